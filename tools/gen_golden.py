@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE modules (build container only).
+
+Runs only where /root/reference exists.  It imports the reference's torch-only network modules
+(stubbing the absent cv2 / torchvision imports that warp_learn/models.py needs at module top),
+loads the synthetic weights of future_urban_scene_generation_amd.synth into them through
+load_state_dict, feeds the synthetic inputs, and stores inputs-by-seed + expected outputs.
+The reference source never leaves this container: fixtures are data only.
+
+Usage:  python -B tools/gen_golden.py [--check-oracle]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+import warnings
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("FUSG_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+cv2 = types.ModuleType("cv2")
+cv2.FILLED = -1                                   # utils/keypoint_utils.py:149 default arg
+sys.modules["cv2"] = cv2
+tv = types.ModuleType("torchvision")
+tvt = types.ModuleType("torchvision.transforms")
+tvt.ToTensor = object
+tvt.Normalize = object
+tv.transforms = tvt
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.transforms"] = tvt
+
+import numpy as np                                # noqa: E402
+import torch                                      # noqa: E402
+
+warnings.filterwarnings("ignore")
+from argparse import Namespace                    # noqa: E402
+
+from stacked_hourglass.models import HourglassNet                   # noqa: E402  (reference)
+from warp_learn.models import G_Resnet                              # noqa: E402  (reference)
+from vunet.models import Vunet_fix_res                              # noqa: E402  (reference)
+from edgeconnect.networks import EdgeGenerator, InpaintGenerator    # noqa: E402  (reference)
+from utils.keypoint_utils import get_maxima as ref_get_maxima       # noqa: E402  (reference)
+from warp_learn.planes_utils import to_image as ref_to_image        # noqa: E402  (reference)
+from utils.misc_utils import to_tensor as ref_to_tensor             # noqa: E402  (reference)
+
+from future_urban_scene_generation_amd.synth import synth_state_dict, schema_of, synth_inputs  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+SEED = 0
+
+
+def build():
+    nets = {
+        "hg": HourglassNet(num_stacks=2, num_blocks=1, num_classes=12),          # run_test.py:62
+        "icn": G_Resnet(21),                                                     # run_test.py:74
+        "vunet": Vunet_fix_res(Namespace(up_mode="subpixel", w_norm=True,        # run_test.py:82
+                                         drop_prob=0.2, vunet_256=True)),
+        "edge": EdgeGenerator(use_spectral_norm=True),                           # edgeconnect/models.py:61
+        "inpaint": InpaintGenerator(),                                           # edgeconnect/models.py:153
+    }
+    sds = {}
+    for name, net in nets.items():
+        schema = schema_of(net.state_dict())
+        with open(os.path.join(GOLD, f"schema_{name}.json"), "w") as f:
+            json.dump({k: [list(s), d] for k, (s, d) in schema.items()}, f, indent=0)
+        sd = synth_state_dict(name, schema, SEED)
+        net.load_state_dict(sd)
+        net.eval()
+        sds[name] = sd
+    return nets, sds
+
+
+def npz(name, **arrs):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-oracle", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_grad_enabled(False)
+    nets, sds = build()
+    manifest = {"seed": SEED, "torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
+    if args.check_oracle:
+        import oracle
+
+    # ---------------- hourglass (+ get_maxima integer contract) -----------------
+    for tag, (B, R) in {"hg_b1_r256": (1, 256), "hg_b2_r128": (2, 128)}.items():
+        x = synth_inputs("hg", B, R, SEED)["x"]
+        out = nets["hg"](x)["heatmaps"]
+        up = torch.nn.functional.interpolate(out[-1], (R, R))                   # trajectory_inference.py:76-77
+        kp = ref_get_maxima(up, 0.5)                                            # :78
+        idx = out[-1].reshape(B, 12, -1).argmax(dim=2)
+        npz(tag, hm0=out[0], hm1=out[1], argmax=idx, maxima=kp)
+        manifest["cases"][tag] = {"net": "hg", "batch": B, "res": R}
+        if args.check_oracle:
+            o = oracle.hourglass_forward(sds["hg"], x)["heatmaps"]
+            print("   oracle==ref:", torch.equal(o[0], out[0]), torch.equal(o[1], out[1]),
+                  np.array_equal(oracle.heatmap_argmax(o[1]), idx.numpy()),
+                  np.array_equal(oracle.get_maxima(o[1]), kp))
+
+    # ---------------- ICN --------------------------------------------------------
+    for tag, (B, R) in {"icn_b1_r256": (1, 256), "icn_b2_r64": (2, 64)}.items():
+        x = synth_inputs("icn", B, R, SEED)["x"]
+        out = nets["icn"](x)
+        img = np.stack([ref_to_image(out[b], from_LAB=False) for b in range(B)])   # planes_utils.py:96 (no LAB: cv2 absent)
+        npz(tag, out=out, img_u8=img)
+        manifest["cases"][tag] = {"net": "icn", "batch": B, "res": R}
+        if args.check_oracle:
+            o = oracle.icn_forward(sds["icn"], x)
+            print("   oracle==ref:", torch.equal(o, out), np.array_equal(oracle.to_image_u8(o), img))
+
+    # ---------------- VUnet: traj_test first-frame sequence, later frame, and forward() -------
+    vu = nets["vunet"]
+    for tag, (B, R) in {"vunet_b1_r256": (1, 256), "vunet_b2_r128": (2, 128)}.items():
+        i = synth_inputs("vunet", B, R, SEED)
+        torch.manual_seed(1234)
+        eo, es = vu.forward_enc_up(i["x"])                                       # trajectory_inference.py:230
+        mu_app, z_app = vu.forward_enc_down(eo, es)                              # :231
+        do, ds = vu.forward_dec_up(i["y_tilde"])                                 # :232
+        ds_keep = [t.clone() for t in ds]
+        xt, mu_s, z_s = vu.forward_dec_down(do, ds, mu_app)                      # :233 (mu_app!)
+        assert len(ds) == 0
+        img = np.stack([ref_to_image(xt[b], from_LAB=False) for b in range(B)])
+        # later frame (trajectory_inference.py:424-426): new y_tilde, mu_app reused, 8 draws
+        y2 = synth_inputs("vunet", B, R, SEED + 1)["y_tilde"]
+        torch.manual_seed(4321)
+        do2, ds2 = vu.forward_dec_up(y2)
+        xt2, _, _ = vu.forward_dec_down(do2, ds2, mu_app)
+        # Vunet_fix_res.forward (models.py:461-481; passes z_app); only valid at 256
+        arrs = dict(enc_out0=eo[0], enc_out1=eo[1], enc_skip0=es[0], enc_skip1=es[1],
+                    mu_app0=mu_app[0], mu_app1=mu_app[1], z_app0=z_app[0], z_app1=z_app[1],
+                    dec_out=do[0], x_tilde=xt, mu_s0=mu_s[0], mu_s1=mu_s[1], z_s0=z_s[0], z_s1=z_s[1],
+                    img_u8=img, x_tilde_later=xt2,
+                    skip_sums=np.array([float(t.double().sum()) for t in ds_keep]),
+                    skip_abs=np.array([float(t.double().abs().sum()) for t in ds_keep]))
+        for k in (0, 5, 13):
+            arrs[f"skip{k}_corner"] = ds_keep[k][:, :, :8, :8]
+        if R == 256:
+            torch.manual_seed(999)
+            f_xt, f_mu_app, f_mu_shape = vu(i["y_tilde"], i["x"])
+            arrs.update(fwd_x_tilde=f_xt, fwd_mu_shape0=f_mu_shape[0])
+        npz(tag, **arrs)
+        manifest["cases"][tag] = {"net": "vunet", "batch": B, "res": R, "noise_seed": 1234,
+                                  "later_seed": 4321, "fwd_seed": 999}
+        if args.check_oracle:
+            sd = sds["vunet"]
+            torch.manual_seed(1234)
+            a, b_ = oracle.vunet_enc_up(sd, i["x"])
+            m, z = oracle.vunet_enc_down(sd, a, b_)
+            c, d = oracle.vunet_dec_up(sd, i["y_tilde"])
+            ok_sk = all(torch.equal(p, q) for p, q in zip(d, ds_keep))
+            o_xt, o_mu, o_z = oracle.vunet_dec_down(sd, c, d, m)
+            print("   oracle==ref:", torch.equal(a[1], eo[1]), torch.equal(m[1], mu_app[1]), torch.equal(z[0], z_app[0]),
+                  ok_sk, torch.equal(o_xt, xt), torch.equal(o_mu[0], mu_s[0]), torch.equal(o_z[1], z_s[1]))
+            torch.manual_seed(4321)
+            c, d = oracle.vunet_dec_up(sd, y2)
+            print("   later  ==ref:", torch.equal(oracle.vunet_dec_down(sd, c, d, m)[0], xt2))
+            if R == 256:
+                torch.manual_seed(999)
+                print("   fwd    ==ref:", torch.equal(oracle.vunet_forward(sd, i["y_tilde"], i["x"])[0], f_xt))
+
+    # ---------------- EdgeConnect (model-wrapper forwards restated from models.py:130-135,236-240) ----
+    for tag, (B, R) in {"ec_b1_r256": (1, 256), "ec_b2_r64": (2, 64)}.items():
+        i = synth_inputs("edge", B, R, SEED)
+        m = i["mask"]
+        # EdgeModel.forward (edgeconnect/models.py:130-135) - edgeconnect.models itself needs torchvision
+        e_in = torch.cat((i["gray"] * (1 - m) + m, i["edge"] * (1 - m), m), dim=1)
+        e_out = nets["edge"](e_in)
+        # InpaintingModel.forward (:236-240), fed with the edge model's output (trajectory_inference.py:124-125)
+        p_in = torch.cat((i["img"] * (1 - m).float() + m, e_out), dim=1)
+        p_out = nets["inpaint"](p_in)
+        merged = p_out * m + i["img"] * (1 - m)                                   # trajectory_inference.py:126
+        merged_u8 = (merged * 255).permute(0, 2, 3, 1).numpy().astype(np.uint8)   # :127-129 (truncation)
+        npz(tag, edge_out=e_out, inpaint_out=p_out, merged_u8=merged_u8)
+        manifest["cases"][tag] = {"net": "edgeconnect", "batch": B, "res": R}
+        if args.check_oracle:
+            oe = oracle.edge_model_forward(sds["edge"], i["gray"], i["edge"], m)
+            oi = oracle.inpaint_model_forward(sds["inpaint"], i["img"], oe, m)
+            print("   oracle==ref:", torch.equal(oe, e_out), torch.equal(oi, p_out))
+
+    # ---------------- host helpers: to_tensor / to_image quantisation ------------
+    g = torch.Generator().manual_seed(7)
+    u8 = (torch.rand(16, 16, 3, generator=g) * 256).floor().clamp(0, 255).to(torch.uint8).numpy()
+    t = ref_to_tensor(u8)                                                         # utils/misc_utils.py:35
+    xs = torch.linspace(-1.2, 1.2, 3 * 64 * 64).reshape(3, 64, 64)
+    npz("host_helpers", u8=u8, to_tensor=t, ramp=xs, ramp_u8=ref_to_image(xs, from_LAB=False))
+    if args.check_oracle:
+        print("   oracle==ref:", torch.equal(oracle.to_tensor_pm1(u8), t),
+              np.array_equal(oracle.to_image_u8(xs), ref_to_image(xs, from_LAB=False)))
+
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
