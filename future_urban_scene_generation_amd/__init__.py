@@ -1,0 +1,39 @@
+"""MI355X-native per-vehicle novel-view synthesis path (stacked-hourglass keypoints ->
+Warp&Learn ICN -> VUnet appearance transfer -> EdgeConnect inpainting).
+
+Drop-in module packages (same class names, constructor arguments, state_dict schema and forward
+signatures as the reference's) live in the sub-packages ``stacked_hourglass``, ``warp_learn``,
+``vunet`` and ``edgeconnect``; ``install()`` aliases them under the reference's top-level import
+names so that ``run_test.py`` / ``trajectory_inference.py`` pick them up unchanged.
+"""
+import importlib
+import sys
+
+__version__ = "0.1.0"
+
+_ALIASES = {
+    "stacked_hourglass": "future_urban_scene_generation_amd.stacked_hourglass",
+    "stacked_hourglass.models": "future_urban_scene_generation_amd.stacked_hourglass.models",
+    "warp_learn.models": "future_urban_scene_generation_amd.warp_learn.models",
+    "vunet": "future_urban_scene_generation_amd.vunet",
+    "vunet.models": "future_urban_scene_generation_amd.vunet.models",
+    "vunet.layers": "future_urban_scene_generation_amd.vunet.layers",
+    "edgeconnect.networks": "future_urban_scene_generation_amd.edgeconnect.networks",
+    "edgeconnect.models": "future_urban_scene_generation_amd.edgeconnect.models",
+}
+
+
+def install(names=None) -> None:
+    """Register the drop-in modules in ``sys.modules`` under the reference's import names.
+
+    Only the network modules are replaced; ``warp_learn`` and ``edgeconnect`` keep resolving their
+    other sub-modules (planes_utils, config, ...) from the reference checkout on ``sys.path``."""
+    for alias, target in _ALIASES.items():
+        if names is not None and alias.split(".")[0] not in names:
+            continue
+        mod = importlib.import_module(target)
+        sys.modules[alias] = mod
+        if "." in alias:
+            parent, leaf = alias.rsplit(".", 1)
+            if parent in sys.modules:
+                setattr(sys.modules[parent], leaf, mod)

@@ -1,0 +1,95 @@
+// libfusg: error reporting, version, and the opt-in per-kernel HIP-event profiler.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+namespace fusg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiler: event pairs recorded on the launch stream, resolved lazily in fusg_prof_read ----
+struct ProfKind {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+    double ms = 0.0, flops = 0.0;
+    long launches = 0;
+    hipEvent_t cur_begin = nullptr;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static ProfKind g_kinds[2];
+
+static hipEvent_t get_event(ProfKind& k) {
+    if (!k.pool.empty()) { hipEvent_t e = k.pool.back(); k.pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(int kind, hipStream_t s, double flops) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfKind& k = g_kinds[kind];
+    k.cur_begin = get_event(k);
+    k.flops += flops;
+    k.launches += 1;
+    (void)hipEventRecord(k.cur_begin, s);
+}
+
+void prof_end(int kind, hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfKind& k = g_kinds[kind];
+    if (!k.cur_begin) return;
+    hipEvent_t e = get_event(k);
+    (void)hipEventRecord(e, s);
+    k.pending.emplace_back(k.cur_begin, e);
+    k.cur_begin = nullptr;
+}
+
+}  // namespace fusg
+
+using namespace fusg;
+
+extern "C" int fusg_version(void) { return FUSG_VERSION; }
+extern "C" const char* fusg_last_error(void) { return g_err; }
+extern "C" const char* fusg_arch(void) { return "gfx950"; }
+extern "C" int fusg_sizeof_tensor(void) { return (int)sizeof(fusg_tensor); }
+extern "C" int fusg_sizeof_conv_desc(void) { return (int)sizeof(fusg_conv_desc); }
+
+extern "C" void fusg_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void fusg_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfKind& k : g_kinds) {
+        for (auto& pr : k.pending) { k.pool.push_back(pr.first); k.pool.push_back(pr.second); }
+        k.pending.clear();
+        k.ms = 0.0; k.flops = 0.0; k.launches = 0; k.cur_begin = nullptr;
+    }
+}
+
+extern "C" int fusg_prof_read(int kind, double* total_ms, int64_t* launches, double* flops) {
+    if (kind < 0 || kind > 1) { set_error("prof_read: kind %d", kind); return FUSG_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfKind& k = g_kinds[kind];
+    for (auto& pr : k.pending) {
+        if (hipEventSynchronize(pr.second) != hipSuccess) { set_error("prof_read: event sync failed"); return FUSG_ERR_LAUNCH; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) k.ms += ms;
+        k.pool.push_back(pr.first);
+        k.pool.push_back(pr.second);
+    }
+    k.pending.clear();
+    if (total_ms) *total_ms = k.ms;
+    if (launches) *launches = k.launches;
+    if (flops) *flops = k.flops;
+    return FUSG_OK;
+}

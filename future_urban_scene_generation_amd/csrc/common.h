@@ -1,0 +1,52 @@
+// Shared host-side helpers for libfusg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/fusg.h"
+
+namespace fusg {
+
+void set_error(const char* fmt, ...);
+
+#define FUSG_CHECK(cond, ...)                         \
+    do {                                              \
+        if (!(cond)) {                                \
+            fusg::set_error(__VA_ARGS__);             \
+            return FUSG_ERR_INVALID;                  \
+        }                                             \
+    } while (0)
+
+#define FUSG_LAUNCH_CHECK(what)                                                    \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            fusg::set_error("%s: %s", what, hipGetErrorString(e__));               \
+            return FUSG_ERR_LAUNCH;                                                \
+        }                                                                          \
+    } while (0)
+
+// NHWC-physical: channels contiguous, dense pixels with channel stride Cs (= sw).
+static inline bool is_nhwc(const fusg_tensor& t) {
+    if (!t.data || t.dtype != FUSG_F32) return false;
+    if (t.c > 1 && t.sc != 1) return false;
+    if (t.sw < t.c || (t.sw & 3)) return false;
+    if (t.h > 1 && t.sh != t.w * t.sw) return false;
+    if (t.n > 1 && t.sn != t.h * t.w * t.sw) return false;
+    if (((uintptr_t)t.data) & 15) return false;
+    return true;
+}
+
+static inline bool same_nhw(const fusg_tensor& a, const fusg_tensor& b) {
+    return a.n == b.n && a.h == b.h && a.w == b.w;
+}
+static inline bool same_shape(const fusg_tensor& a, const fusg_tensor& b) {
+    return same_nhw(a, b) && a.c == b.c;
+}
+
+// profiler (api.hip)
+void prof_begin(int kind, hipStream_t s, double flops);
+void prof_end(int kind, hipStream_t s);
+
+}  // namespace fusg

@@ -1,0 +1,315 @@
+"""Thin Python wrappers over the libfusg C ABI (include/fusg.h).
+
+PyTorch is used here only as plumbing: device allocations (caching allocator), the current HIP
+stream, and host<->device copies.  All arithmetic on activations happens inside libfusg kernels.
+Activations are torch tensors of *logical* NCHW shape whose memory is NHWC ("NHWC-physical":
+channels contiguous, channel pitch a multiple of 4) so that callers can still `.cpu().numpy()`
+them like any other tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .pack import ConvPlan
+
+_DT = {torch.float32: L.F32, torch.uint8: L.U8, torch.int32: L.I32}
+
+
+def _require_gpu(t: torch.Tensor, what: str = "input") -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} is on {t.device}: the MI355X-native modules run on a HIP device only "
+                           "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def desc(t: Optional[torch.Tensor]) -> L.Tensor:
+    """fusg_tensor for a 4-D torch tensor (or an absent tensor)."""
+    d = L.Tensor()
+    if t is None:
+        return d
+    assert t.dim() == 4, t.shape
+    d.data = t.data_ptr()
+    d.n, d.c, d.h, d.w = t.shape
+    d.sn, d.sc, d.sh, d.sw = t.stride()
+    d.dtype = _DT[t.dtype]
+    return d
+
+
+def nhwc_empty(b: int, c: int, h: int, w: int, device, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+    """Logical [b, c, h, w] view over a fresh NHWC buffer whose channel pitch is c rounded up to 4."""
+    cp = (c + 3) // 4 * 4
+    buf = (torch.zeros if zero else torch.empty)((b, h, w, cp), device=device, dtype=dtype)
+    t = buf.permute(0, 3, 1, 2)
+    return t if cp == c else t[:, :c]
+
+
+def is_nhwc(t: torch.Tensor) -> bool:
+    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
+        return False
+    b, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return False
+    if sw < c or sw % 4:
+        return False
+    if h > 1 and sh != w * sw:
+        return False
+    if b > 1 and sn != h * w * sw:
+        return False
+    return t.data_ptr() % 16 == 0
+
+
+def copy4d(src: torch.Tensor, dst: torch.Tensor, c_fill: int = 0) -> torch.Tensor:
+    L.check(L.lib().fusg_copy4d(C.byref(desc(src)), C.byref(desc(dst)), int(c_fill), stream_ptr()), "copy4d")
+    return dst
+
+
+def as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` itself if it already is NHWC-physical f32, else a converted copy (channel padding
+    zero-filled).  Used at the module boundary for caller-provided NCHW tensors."""
+    _require_gpu(t)
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if is_nhwc(t):
+        return t
+    b, c, h, w = t.shape
+    cp = (c + 3) // 4 * 4
+    buf = torch.empty((b, h, w, cp), device=t.device, dtype=torch.float32)
+    full = buf.permute(0, 3, 1, 2)
+    copy4d(t, full, cp)
+    return full if cp == c else full[:, :c]
+
+
+def to_nchw(t: torch.Tensor) -> torch.Tensor:
+    """Standard-contiguous NCHW copy (module outputs handed back to the caller)."""
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    return copy4d(t, out, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Stream-ordered split-K scratch, grown on demand (one per device)."""
+    key = str(device)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 22) + 3) // 4, device=device, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
+
+
+def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
+         out_c_off: int = 0, res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
+         pre_op: int = L.PRE_NONE, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_bstride: int = 0,
+         act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
+         ksplit: int = 0) -> torch.Tensor:
+    """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
+    unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result)."""
+    plan.to(x0.device)
+    b, c0, h, w = x0.shape
+    assert c0 == plan.c_split[0], (x0.shape, plan.c_split)
+    if len(plan.c_split) > 1:
+        assert x1 is not None and x1.shape[1] == plan.c_split[1] and x1.shape[0] == b and x1.shape[2:] == x0.shape[2:], \
+            (x0.shape, None if x1 is None else x1.shape, plan.c_split)
+    else:
+        assert x1 is None
+    qh, qw = plan.out_hw(h, w)
+    if plan.nphase == 4:
+        oc, oh, ow = plan.cout, 2 * qh, 2 * qw
+    elif store == L.STORE_D2S:
+        oc, oh, ow = plan.cout // 4, 2 * qh, 2 * qw
+    elif store == L.STORE_S2D:
+        oc, oh, ow = plan.cout * 4, qh // 2, qw // 2
+    else:
+        oc, oh, ow = plan.cout, qh, qw
+    if out is None:
+        out = torch.empty((b, oc, oh, ow), device=x0.device, dtype=torch.float32) if nchw_out \
+            else nhwc_empty(b, oc, oh, ow, x0.device)
+    d = L.ConvDesc()
+    d.src0 = desc(x0)
+    d.src1 = desc(x1)
+    d.dst = desc(out)
+    d.res0 = desc(res0)
+    d.res1 = desc(res1)
+    dev = plan.dev
+    d.wpack = dev["wpack"].data_ptr()
+    d.bias = dev["bias"].data_ptr()
+    d.ktab = dev["ktab"].data_ptr()
+    if pre is not None:
+        d.pre_scale = pre[0].data_ptr()
+        d.pre_shift = pre[1].data_ptr()
+        d.pre_bstride = int(pre_bstride)
+    d.k_pad, d.c0k, d.cout, d.cout_pad = plan.k_pad, plan.c0k, plan.cout, plan.cout_pad
+    d.stride, d.upsample, d.pad_mode = plan.stride, plan.upsample, plan.pad_mode
+    d.pre_op, d.act, d.store_mode = int(pre_op), int(act), int(store)
+    d.qh, d.qw, d.nphase = qh, qw, plan.nphase
+    if plan.nphase == 4:
+        d.out_sy = d.out_sx = 2
+        for ph in range(4):
+            d.out_oy[ph] = ph >> 1
+            d.out_ox[ph] = ph & 1
+    else:
+        d.out_sy = d.out_sx = 1
+    d.dst_c_off = int(out_c_off)
+    d.tile, d.ksplit = int(tile), int(ksplit)
+    lib = L.lib()
+    nbytes = lib.fusg_conv2d_plan(C.byref(d))
+    ws = None
+    if nbytes > 0:
+        ws = _workspace(x0.device, nbytes)
+        d.workspace = ws.data_ptr()
+    L.check(lib.fusg_conv2d(C.byref(d), stream_ptr()), "conv2d")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------------------
+def _nchunk(b: int, c: int, hw: int) -> int:
+    zg = (c // 4 + 63) // 64
+    want = max(1, 1024 // max(1, b * zg))
+    return int(max(1, min(want, max(1, hw // 64), 4096)))
+
+
+def _chan_stats(x: torch.Tensor):
+    b, c, h, w = x.shape
+    n = _nchunk(b, c, h * w)
+    partial = torch.empty((b, n, c, 2), device=x.device, dtype=torch.float32)
+    L.check(L.lib().fusg_chan_stats(C.byref(desc(x)), partial.data_ptr(), n, stream_ptr()), "chan_stats")
+    return partial, n
+
+
+def instnorm_stats(x: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scale, shift) [B, C] such that InstanceNorm2d(x) = x*scale + shift."""
+    b, c = x.shape[:2]
+    partial, n = _chan_stats(x)
+    ss = torch.empty((2, b, c), device=x.device, dtype=torch.float32)
+    L.check(L.lib().fusg_in_finalize(C.byref(desc(x)), partial.data_ptr(), n, float(eps), ss[0].data_ptr(),
+                                     ss[1].data_ptr(), stream_ptr()), "in_finalize")
+    return ss[0], ss[1]
+
+
+def layernorm_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """(scale, shift) [B, C] of the ICN's custom LayerNorm (warp_learn/models.py:26-35)."""
+    b, c = x.shape[:2]
+    partial, n = _chan_stats(x)
+    ss = torch.empty((2, b, c), device=x.device, dtype=torch.float32)
+    L.check(L.lib().fusg_ln_finalize(C.byref(desc(x)), partial.data_ptr(), n, float(eps), gamma.data_ptr(),
+                                     beta.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), stream_ptr()), "ln_finalize")
+    return ss[0], ss[1]
+
+
+def affine_act(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], act: int = L.ACT_NONE,
+               res: Optional[torch.Tensor] = None, bstride: Optional[int] = None) -> torch.Tensor:
+    b, c, h, w = x.shape
+    out = nhwc_empty(b, c, h, w, x.device)
+    if bstride is None:
+        bstride = c
+    L.check(L.lib().fusg_affine_act(C.byref(desc(x)), scale.data_ptr() if scale is not None else None,
+                                    shift.data_ptr() if shift is not None else None, int(bstride), int(act),
+                                    C.byref(desc(res)) if res is not None else None, C.byref(desc(out)), stream_ptr()),
+            "affine_act")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# data movement / small ops
+# ---------------------------------------------------------------------------------------------
+def maxpool2(x: torch.Tensor) -> torch.Tensor:
+    b, c, h, w = x.shape
+    out = nhwc_empty(b, c, h // 2, w // 2, x.device)
+    L.check(L.lib().fusg_maxpool2(C.byref(desc(x)), C.byref(desc(out)), stream_ptr()), "maxpool2")
+    return out
+
+
+def upsample2_add(low: torch.Tensor, up1: torch.Tensor) -> torch.Tensor:
+    out = nhwc_empty(*up1.shape, up1.device)
+    L.check(L.lib().fusg_upsample2_add(C.byref(desc(low)), C.byref(desc(up1)), C.byref(desc(out)), stream_ptr()),
+            "upsample2_add")
+    return out
+
+
+def add4d(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = nhwc_empty(*a.shape, a.device)
+    L.check(L.lib().fusg_add4d(C.byref(desc(a)), C.byref(desc(b)), C.byref(desc(out)), stream_ptr()), "add4d")
+    return out
+
+
+def space_to_depth2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    b, c, h, w = x.shape
+    if out is None:
+        out = nhwc_empty(b, 4 * c, h // 2, w // 2, x.device)
+    L.check(L.lib().fusg_space_to_depth2(C.byref(desc(x)), C.byref(desc(out)), stream_ptr()), "space_to_depth2")
+    return out
+
+
+def depth_to_space2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    b, c, h, w = x.shape
+    if out is None:
+        out = nhwc_empty(b, c // 4, 2 * h, 2 * w, x.device)
+    L.check(L.lib().fusg_depth_to_space2(C.byref(desc(x)), C.byref(desc(out)), stream_ptr()), "depth_to_space2")
+    return out
+
+
+def ec_inputs(images: torch.Tensor, edges: torch.Tensor, masks: torch.Tensor, mode: int) -> torch.Tensor:
+    b, _, h, w = images.shape
+    out = nhwc_empty(b, 4, h, w, images.device)
+    L.check(L.lib().fusg_ec_inputs(C.byref(desc(images)), C.byref(desc(edges)), C.byref(desc(masks)), C.byref(desc(out)),
+                                   int(mode), stream_ptr()), "ec_inputs")
+    return out if mode == 1 else out[:, :3]
+
+
+def argmax_hw(x: torch.Tensor) -> torch.Tensor:
+    """int32 [B, C] row-major first-occurrence argmax over H*W."""
+    _require_gpu(x)
+    b, c = x.shape[:2]
+    idx = torch.empty((b, c), device=x.device, dtype=torch.int32)
+    L.check(L.lib().fusg_argmax_hw(C.byref(desc(x)), idx.data_ptr(), stream_ptr()), "argmax_hw")
+    return idx
+
+
+def to_image_u8(x: torch.Tensor) -> torch.Tensor:
+    """uint8 [B, H, W, C] = trunc(clip((x+1)/2*255)) (to_image without the LAB branch)."""
+    _require_gpu(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), device=x.device, dtype=torch.uint8)
+    L.check(L.lib().fusg_to_image_u8(C.byref(desc(x)), C.byref(desc(out.permute(0, 3, 1, 2))), stream_ptr()), "to_image_u8")
+    return out
+
+
+def merge_u8(out_: torch.Tensor, img: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """uint8 [B, H, W, C] = trunc((out*m + img*(1-m))*255) (trajectory_inference.py:126-129)."""
+    b, c, h, w = out_.shape
+    dst = torch.empty((b, h, w, c), device=out_.device, dtype=torch.uint8)
+    L.check(L.lib().fusg_merge_u8(C.byref(desc(out_)), C.byref(desc(img)), C.byref(desc(mask)),
+                                  C.byref(desc(dst.permute(0, 3, 1, 2))), stream_ptr()), "merge_u8")
+    return dst
+
+
+# ---------------------------------------------------------------------------------------------
+# profiler hooks (bench.py roofline leg)
+# ---------------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    L.lib().fusg_prof_enable(1 if on else 0)
+
+
+def prof_reset() -> None:
+    L.lib().fusg_prof_reset()
+
+
+def prof_read(kind: int = 0):
+    ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+    L.check(L.lib().fusg_prof_read(kind, C.byref(ms), C.byref(n), C.byref(fl)), "prof_read")
+    return ms.value, n.value, fl.value

@@ -1,0 +1,177 @@
+"""Load-time weight pre-packing for the fused implicit-GEMM convolution (csrc/conv_igemm.hip).
+
+Everything here is host-side, one-off work done when a module's parameters change
+(``load_state_dict`` / ``.to(device)``): folding of the re-parametrisations that are pure functions
+of the parameters (weight_norm, spectral_norm, conv-following eval BatchNorm), re-layout of the
+filter into the kernel's ``[cout_pad][k_pad]`` K-contiguous panel, and construction of the k-table
+that drives the on-the-fly im2col gather (see include/fusg.h, ``fusg_conv_desc``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+BK = 32
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class ConvPlan:
+    """Packed parameters + static geometry of one convolution call site (host copies; `.dev`
+    holds the uploaded device tensors)."""
+    wpack: torch.Tensor            # [nphase, cout_pad, k_pad] f32
+    bias: torch.Tensor             # [cout_pad] f32
+    ktab: torch.Tensor             # [nphase, k_pad // 4, 2] int32
+    cout: int
+    cout_pad: int
+    k_pad: int
+    c_split: Tuple[int, ...]       # logical concat channel counts (C0,) or (C0, C1)
+    c0k: int                       # K-channels taken from src0 (multiple of 4)
+    c1k: int
+    kh: int
+    kw: int
+    stride: int = 1
+    pad: int = 0
+    dil: int = 1
+    pad_mode: int = 0              # 0 zero, 1 reflect
+    upsample: int = 0
+    nphase: int = 1                # 4 = ConvTranspose2d(k4, s2, p1)
+    flops_per_pixel: float = 0.0   # algorithmic 2*MAC per q-space output pixel (all phases: per input pixel)
+    dev: dict = field(default_factory=dict)
+
+    def to(self, device) -> "ConvPlan":
+        key = str(device)
+        if self.dev.get("key") != key:
+            self.dev = {"key": key,
+                        "wpack": self.wpack.to(device).contiguous(),
+                        "bias": self.bias.to(device).contiguous(),
+                        "ktab": self.ktab.to(device).contiguous()}
+        return self
+
+    def out_hw(self, h: int, w: int) -> Tuple[int, int]:
+        """q-space output grid for an input of h x w."""
+        if self.nphase == 4:
+            return h, w
+        hv, wv = h << self.upsample, w << self.upsample
+        return ((hv + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1,
+                (wv + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1)
+
+
+def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):
+    x = (dy & 0xFFFF) | ((dx & 0xFFFF) << 16)
+    y = (coff & 0x3FFFFFFF) | (src << 30) | ((1 << 31) if invalid else 0)
+    # to signed int32
+    x = x - (1 << 32) if x >= (1 << 31) else x
+    y = y - (1 << 32) if y >= (1 << 31) else y
+    return x, y
+
+
+def _pack_panel(w: torch.Tensor, taps: Sequence[Tuple[int, int, int, int]], c_split: Sequence[int]):
+    """w: [cout, cin, kh, kw] (correlation form).  taps: list of (ky, kx, dy, dx).
+    Returns (panel [cout_pad, k_pad], ktab [k_pad/4, 2]) for K order (tap, concat channel)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert sum(c_split) == cin, (c_split, cin)
+    c0 = c_split[0]
+    c1 = c_split[1] if len(c_split) > 1 else 0
+    c0k, c1k = _ru(c0, 4), _ru(c1, 4)
+    ctot = c0k + c1k
+    k = len(taps) * ctot
+    k_pad = _ru(k, BK)
+    cout_pad = _ru(cout, 32)
+    panel = torch.zeros(cout_pad, k_pad, dtype=torch.float32)
+    tab = np.zeros((k_pad // 4, 2), dtype=np.int64)
+    for t, (ky, kx, dy, dx) in enumerate(taps):
+        base = t * ctot
+        panel[:cout, base:base + c0] = w[:, :c0, ky, kx]
+        if c1:
+            panel[:cout, base + c0k:base + c0k + c1] = w[:, c0:, ky, kx]
+        for q in range(ctot // 4):
+            cc = q * 4
+            src, coff = (0, cc) if cc < c0k else (1, cc - c0k)
+            tab[(base + cc) // 4] = _entry(dy, dx, coff, src)
+    for q in range(k // 4, k_pad // 4):
+        tab[q] = _entry(0, 0, 0, 0, invalid=True)
+    return panel, torch.from_numpy(tab.astype(np.int32)), c0k, c1k, k_pad, cout_pad
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], *, c_split: Optional[Sequence[int]] = None,
+              stride: int = 1, pad: int = 0, dil: int = 1, pad_mode: int = 0, upsample: int = 0) -> ConvPlan:
+    """nn.Conv2d-style filter [cout, cin, kh, kw] -> ConvPlan."""
+    w = weight.detach().to("cpu", torch.float32)
+    cout, cin, kh, kw = w.shape
+    c_split = tuple(c_split) if c_split is not None else (cin,)
+    taps = [(ky, kx, ky * dil - pad, kx * dil - pad) for ky in range(kh) for kx in range(kw)]
+    panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(w, taps, c_split)
+    b = torch.zeros(cout_pad, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.detach().to("cpu", torch.float32)
+    return ConvPlan(wpack=panel[None].contiguous(), bias=b, ktab=tab[None].contiguous(), cout=cout, cout_pad=cout_pad,
+                    k_pad=k_pad, c_split=c_split, c0k=c0k, c1k=c1k, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil,
+                    pad_mode=pad_mode, upsample=upsample, nphase=1, flops_per_pixel=2.0 * cout * cin * kh * kw)
+
+
+def pack_conv_transpose_k4s2p1(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> ConvPlan:
+    """nn.ConvTranspose2d(k=4, s=2, p=1) filter [cin, cout, 4, 4] -> four 2x2 phase convolutions.
+
+    out[2q + py] gathers, per axis, ky in {1, 3} with input offsets {0, -1} (py = 0) or ky in {0, 2}
+    with offsets {+1, 0} (py = 1): oy = 2*iy - 1 + ky."""
+    w = weight.detach().to("cpu", torch.float32)
+    cin, cout, kh, kw = w.shape
+    assert kh == 4 and kw == 4
+    wc = w.permute(1, 0, 2, 3).contiguous()          # [cout, cin, ky, kx], no flip needed with the mapping above
+    axis = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}
+    panels, tabs = [], []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = [(ky, kx, dy, dx) for (ky, dy) in axis[py] for (kx, dx) in axis[px]]
+            panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(wc, taps, (cin,))
+            panels.append(panel)
+            tabs.append(tab)
+    b = torch.zeros(cout_pad, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.detach().to("cpu", torch.float32)
+    return ConvPlan(wpack=torch.stack(panels).contiguous(), bias=b, ktab=torch.stack(tabs).contiguous(), cout=cout,
+                    cout_pad=cout_pad, k_pad=k_pad, c_split=(cin,), c0k=c0k, c1k=c1k, kh=4, kw=4, stride=1, pad=0, dil=1,
+                    pad_mode=0, upsample=0, nphase=4, flops_per_pixel=2.0 * cout * cin * 16)
+
+
+# ---- parameter folds (pure functions of the parameters; exact formulas of the reference's wrappers) ----
+
+def fold_weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """torch.nn.utils.weight_norm(dim=0) (vunet/layers.py:29-31): w = g * v / ||v||, norm over dims 1..3."""
+    v = v.detach().to("cpu", torch.float32)
+    g = g.detach().to("cpu", torch.float32)
+    return torch._weight_norm(v, g, 0)
+
+
+def fold_spectral_norm(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """nn.utils.spectral_norm in eval mode (edgeconnect/networks.py:206-210): w = w_orig / (u . W_mat v)
+    with the stored u, v; W_mat flattens around dim 1 for ConvTranspose2d."""
+    w = w_orig.detach().to("cpu", torch.float32)
+    wm = w.permute(1, 0, 2, 3).reshape(w.shape[1], -1) if transposed else w.reshape(w.shape[0], -1)
+    sigma = torch.dot(u.detach().to("cpu", torch.float32), torch.mv(wm, v.detach().to("cpu", torch.float32)))
+    return w / sigma
+
+
+def bn_scale_shift(weight, bias, running_mean, running_var, eps: float = 1e-5):
+    """Eval BatchNorm2d as y = x*scale + shift (computed in fp64, rounded once)."""
+    w = weight.detach().to("cpu", torch.float64)
+    b = bias.detach().to("cpu", torch.float64)
+    rm = running_mean.detach().to("cpu", torch.float64)
+    rv = running_var.detach().to("cpu", torch.float64)
+    scale = w / torch.sqrt(rv + eps)
+    shift = b - rm * scale
+    return scale.to(torch.float32), shift.to(torch.float32)
+
+
+def fold_bn_after_conv(w: torch.Tensor, b: Optional[torch.Tensor], scale: torch.Tensor, shift: torch.Tensor):
+    """conv followed directly by eval BatchNorm: w' = w*scale[cout], b' = b*scale + shift."""
+    w = w.detach().to("cpu", torch.float32)
+    b0 = torch.zeros(w.shape[0]) if b is None else b.detach().to("cpu", torch.float32)
+    return w * scale.view(-1, 1, 1, 1), b0 * scale + shift

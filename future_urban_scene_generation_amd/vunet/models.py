@@ -1,0 +1,322 @@
+"""Drop-in for the reference's ``vunet.models`` on MI355X.
+
+Public surface kept (vunet/models.py:191-481): ``Vunet_fix_res(args)`` with ``args`` an
+``argparse.Namespace(up_mode, w_norm, drop_prob, vunet_256)``; the reference's ``state_dict`` schema
+(336 entries ``...conv.{bias,weight_g,weight_v}`` for the shipped configuration); and the five
+entry points ``forward_enc_up / forward_enc_down / forward_dec_up / forward_dec_down / forward``
+with the same argument order, return structure and side effect (``forward_dec_down`` pops the
+caller's ``skips`` list empty).
+
+Execution notes
+  * weight_norm is a pure function of the parameters: folded once at pack time.
+  * ``Residual`` = ``x + conv3x3(ELU(cat[x, skip]))`` is ONE launch: the concat is two gather
+    sources, ELU is applied while staging the tile, the residual add is the epilogue.
+  * ``UpSample('subpixel')`` = 3x3 conv with a DepthToSpace(DCR) store permutation: one launch.
+  * ``Sampler`` noise is drawn exactly like the reference (vunet/layers.py:163-167): on the CPU
+    default generator, shape ``mu.size()``, in the reference's call order - so the same
+    ``torch.manual_seed`` reproduces the reference's stochastic output.
+  * The four sampler means of an autoregressive block are written straight into the channel slices
+    of the buffer that DepthToSpace consumes (no torch.cat).
+"""
+from __future__ import annotations
+
+import argparse
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops, pack
+from ..nn_base import FusedNet, WNConvP
+from .layers import (Activation, DepthToSpace, DownSample, MyConv2d, NiN, Residual, Sampler, SpaceToDepth,
+                     UpSample)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter-holder blocks (same attribute names / registration order as the reference)
+# ------------------------------------------------------------------------------------------------
+def _res(c_in, c_out, dp, wn):
+    return Residual(c_in=c_in, c_out=c_out, activation=Activation("elu"), drop_prob=dp, w_norm=wn)
+
+
+class AutoRegressiveBlock(nn.Module):
+    def __init__(self, drop_prob, w_norm):
+        super().__init__()
+        self.s2d = SpaceToDepth(2)
+        self.d2s = DepthToSpace(2)
+        self.residual_init = _res(256, 128, drop_prob, w_norm)
+        self.sampler_0 = Sampler(512, 128, w_norm)
+        self.residual_0 = _res(1024, 512, drop_prob, w_norm)
+        self.sampler_1 = Sampler(512, 128, w_norm)
+        self.residual_1 = _res(1024, 512, drop_prob, w_norm)
+        self.sampler_2 = Sampler(512, 128, w_norm)
+        self.residual_2 = _res(1024, 512, drop_prob, w_norm)
+        self.sampler_3 = Sampler(512, 128, w_norm)
+        self.nin_0 = NiN(128, 512, w_norm)
+        self.nin_1 = NiN(128, 512, w_norm)
+        self.nin_2 = NiN(128, 512, w_norm)
+        self.residual_s2d = _res(128, 128, drop_prob, w_norm)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, c_in, c_out, drop_prob, w_norm):
+        super().__init__()
+        self.down = DownSample(c_in, c_out, w_norm)
+        self.residual_0 = _res(c_out, c_out, drop_prob, w_norm)
+        self.residual_1 = _res(c_out, c_out, drop_prob, w_norm)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, c_in, c_middle, c_out, up_mode, drop_prob, w_norm):
+        super().__init__()
+        self.residual_0 = _res(c_in, c_middle, drop_prob, w_norm)
+        self.residual_1 = _res(c_in, c_middle, drop_prob, w_norm)
+        self.up = UpSample(c_middle, c_out, w_norm, up_mode)
+
+
+class InitBlock(nn.Module):
+    def __init__(self, c_in, c_out, drop_prob, w_norm):
+        super().__init__()
+        self.nin = NiN(c_in, c_out, w_norm)
+        self.residual_0 = _res(c_out, c_out, drop_prob, w_norm)
+        self.residual_1 = _res(c_out, c_out, drop_prob, w_norm)
+
+
+class EndBlock(nn.Module):
+    def __init__(self, c_in, c_middle, c_out, drop_prob, w_norm):
+        super().__init__()
+        self.residual_0 = _res(c_in, c_middle, drop_prob, w_norm)
+        self.residual_1 = _res(c_in, c_middle, drop_prob, w_norm)
+        self.conv = MyConv2d(c_middle, c_out, 3, 1, 1, w_norm)
+
+
+class Vunet_fix_res(FusedNet):
+    def __init__(self, args: argparse.Namespace):
+        super().__init__()
+        self.args = args
+        wn = self.w_norm = args.w_norm
+        dp = self.drop_prob = args.drop_prob
+        um = self.up_mode = args.up_mode
+        self.vunet_256 = args.vunet_256
+        # appearance encoder
+        self.app_encoder_1 = InitBlock(6, 128, dp, wn)
+        self.app_encoder_1_a = DownBlock(128, 128, dp, wn)
+        self.app_encoder_1_b = DownBlock(128, 128, dp, wn)
+        if self.vunet_256:
+            self.app_encoder_1_c = DownBlock(128, 128, dp, wn)
+        self.app_encoder_2 = DownBlock(128, 128, dp, wn)
+        self.app_encoder_3 = DownBlock(128, 128, dp, wn)
+        self.app_encoder_4 = DownBlock(128, 128, dp, wn)
+        self.app_skip_3_c = NiN(128, 128, wn)
+        self.app_skip_4_c = NiN(128, 128, wn)
+        # appearance decoder
+        self.app_bottleneck = MyConv2d(128, 128, 1, 1, 0, wn)
+        self.app_decoder_1_a = _res(256, 128, dp, wn)
+        self.app_decoder_1_b = Sampler(128, 128, wn)
+        self.app_decoder_1_c = MyConv2d(256, 128, 1, 1, 0, wn)
+        self.app_decoder_1_d = _res(256, 128, dp, wn)
+        self.app_decoder_1_e = UpSample(128, 128, wn, um)
+        self.app_decoder_2_a = _res(128, 128, dp, wn)
+        self.app_decoder_2_b = Sampler(128, 128, wn)
+        # shape encoder
+        self.shape_encoder_1 = InitBlock(3, 32, dp, wn)
+        if self.vunet_256:
+            self.shape_encoder_1_a = DownBlock(32, 32, dp, wn)
+        self.shape_encoder_2 = DownBlock(32, 64, dp, wn)
+        self.shape_encoder_3 = DownBlock(64, 128, dp, wn)
+        self.shape_encoder_4 = DownBlock(128, 128, dp, wn)
+        self.shape_encoder_5 = DownBlock(128, 128, dp, wn)
+        self.shape_encoder_6 = DownBlock(128, 128, dp, wn)
+        self.shape_skip_1_b = NiN(32, 32, wn)
+        self.shape_skip_1_c = NiN(32, 32, wn)
+        if self.vunet_256:
+            self.shape_skip_1_a_b = NiN(32, 32, wn)
+            self.shape_skip_1_a_c = NiN(32, 32, wn)
+        for i, c in ((2, 64), (3, 128), (4, 128), (5, 128), (6, 128)):
+            setattr(self, f"shape_skip_{i}_b", NiN(c, c, wn))
+            setattr(self, f"shape_skip_{i}_c", NiN(c, c, wn))
+        # shape decoder
+        self.shape_bottleneck = MyConv2d(128, 128, 1, 1, 0, wn)
+        self.shape_decoder_1 = AutoRegressiveBlock(dp, wn)
+        self.shape_decoder_1_n = NiN(256, 128, wn)
+        self.shape_decoder_1_o = _res(256, 128, dp, wn)
+        self.shape_decoder_1_p = UpSample(128, 128, wn, um)
+        self.shape_decoder_2 = AutoRegressiveBlock(dp, wn)
+        self.shape_decoder_2_n = NiN(256, 128, wn)
+        self.shape_decoder_2_o = _res(256, 128, dp, wn)
+        self.shape_decoder_2_p = UpSample(128, 128, wn, um)
+        self.shape_decoder_3 = UpBlock(256, 128, 128, um, dp, wn)
+        self.shape_decoder_4 = UpBlock(256, 128, 64, um, dp, wn)
+        self.shape_decoder_5 = UpBlock(128, 64, 32, um, dp, wn)
+        if self.vunet_256:
+            self.shape_decoder_5_a = UpBlock(64, 32, 32, um, dp, wn)
+        self.shape_decoder_6 = EndBlock(64, 32, 3, dp, wn)
+
+    # ------------------------------------------------------------------ packing
+    _TWO_SOURCE = {"shape_decoder_1_n.layers.1": (128, 128), "shape_decoder_2_n.layers.1": (128, 128),
+                   "app_decoder_1_c": (128, 128)}
+
+    def _build_plans(self, device) -> dict:
+        parents = {}
+        for pname, pm in self.named_modules():
+            if isinstance(pm, Residual):
+                parents[pname + ".layers.2"] = pm
+        P = {}
+        for name, m in self.named_modules():
+            if not isinstance(m, MyConv2d):
+                continue
+            h = m.conv
+            w = pack.fold_weight_norm(h.weight_v, h.weight_g) if isinstance(h, WNConvP) else h.weight
+            split = self._TWO_SOURCE.get(name)
+            r = parents.get(name)
+            if r is not None and r.c_in != r.c_out:
+                split = (r.c_out, r.c_in - r.c_out)
+            P[name] = pack.pack_conv(w, h.bias, c_split=split, stride=m.stride, pad=m.padding).to(device)
+        return P
+
+    # ------------------------------------------------------------------ fused building blocks
+    def _residual(self, name: str, x, skip=None):
+        return ops.conv(self._plans[name + ".layers.2"], x, skip, pre_op=L.PRE_ELU, res0=x)
+
+    def _nin(self, name: str, x, x1=None):
+        return ops.conv(self._plans[name + ".layers.1"], x, x1, pre_op=L.PRE_ELU)
+
+    def _upsample(self, name: str, x):
+        return ops.conv(self._plans[name + ".depth4x"], x, store=L.STORE_D2S)
+
+    def _sampler(self, name: str, x, mu_out=None, c_off=0, z_out=None):
+        """Sampler (layers.py:163-167).  Returns (mu, z); with mu_out/z_out the results go to the
+        channel slice [c_off, c_off+128) of those buffers."""
+        p = self._plans[name + ".conv"]
+        if mu_out is None:
+            mu = ops.conv(p, x)
+        else:
+            ops.conv(p, x, out=mu_out, out_c_off=c_off)
+            mu = mu_out[:, c_off:c_off + p.cout]
+        noise = torch.randn(*mu.size()).to(mu.device)             # CPU default generator, like the reference
+        z = ops.add4d(mu, noise, None if z_out is None else z_out[:, c_off:c_off + p.cout])
+        return mu, z
+
+    def _init_block(self, name, x):
+        x = self._nin(name + ".nin", x)
+        s0 = x = self._residual(name + ".residual_0", x)
+        s1 = x = self._residual(name + ".residual_1", x)
+        return x, [s0, s1]
+
+    def _down_block(self, name, x):
+        x = ops.conv(self._plans[name + ".down.down"], x)
+        s0 = x = self._residual(name + ".residual_0", x)
+        s1 = x = self._residual(name + ".residual_1", x)
+        return x, [s0, s1]
+
+    def _up_block(self, name, x, skip_a, skip_b):
+        x = self._residual(name + ".residual_0", x, skip_a)
+        x = self._residual(name + ".residual_1", x, skip_b)
+        return self._upsample(name + ".up", x)
+
+    def _ar_block(self, name, x, skip_a, enc_down_mu=None):
+        """AutoRegressiveBlock.forward (reference models.py:56-86)."""
+        x = self._residual(name + ".residual_init", x, skip_a)
+        x_ = ops.space_to_depth2(self._residual(name + ".residual_s2d", x))
+        g = None
+        if enc_down_mu is not None:
+            gs = ops.space_to_depth2(ops.as_nhwc(enc_down_mu))
+            g = [self._nin(f"{name}.nin_{k}", gs[:, 128 * k:128 * (k + 1)]) for k in range(3)]
+        b, _, h, w = x_.shape
+        mus = ops.nhwc_empty(b, 512, h, w, x_.device)
+        zs = ops.nhwc_empty(b, 512, h, w, x_.device)
+        for k in range(4):
+            _, z_k = self._sampler(f"{name}.sampler_{k}", x_, mus, 128 * k, zs)
+            if k < 3:
+                cond = g[k] if g is not None else self._nin(f"{name}.nin_{k}", z_k)
+                x_ = self._residual(f"{name}.residual_{k}", x_, cond)
+        return x, ops.depth_to_space2(mus), ops.depth_to_space2(zs)
+
+    # ------------------------------------------------------------------ reference entry points
+    def forward_enc_up(self, x):
+        self._ensure(x)
+        x = ops.as_nhwc(x)
+        x, _ = self._init_block("app_encoder_1", x)
+        names = ["app_encoder_1_a", "app_encoder_1_b"] + (["app_encoder_1_c"] if self.vunet_256 else []) + \
+                ["app_encoder_2", "app_encoder_3"]
+        for n in names:
+            x, _ = self._down_block(n, x)
+        skips = [self._nin("app_skip_3_c", x)]
+        x, sl = self._down_block("app_encoder_4", x)
+        outputs = [sl[-2], x]
+        skips.append(self._nin("app_skip_4_c", x))
+        return outputs, skips
+
+    def forward_dec_up(self, x):
+        self._ensure(x)
+        x = ops.as_nhwc(x)
+        skips: List[torch.Tensor] = []
+        x, sl = self._init_block("shape_encoder_1", x)
+        skips += [self._nin("shape_skip_1_b", sl[-2]), self._nin("shape_skip_1_c", sl[-1])]
+        if self.vunet_256:
+            x, sl = self._down_block("shape_encoder_1_a", x)
+            skips += [self._nin("shape_skip_1_a_b", sl[-2]), self._nin("shape_skip_1_a_c", sl[-1])]
+        for i in range(2, 7):
+            x, sl = self._down_block(f"shape_encoder_{i}", x)
+            skips += [self._nin(f"shape_skip_{i}_b", sl[-2]), self._nin(f"shape_skip_{i}_c", sl[-1])]
+        return [x], skips
+
+    def forward_enc_down(self, enc_up_outputs: Sequence[torch.Tensor], skips: Sequence[torch.Tensor]):
+        self._ensure(enc_up_outputs[-1])
+        P = self._plans
+        o1, o2 = ops.as_nhwc(enc_up_outputs[-1]), ops.as_nhwc(enc_up_outputs[-2])
+        x = ops.conv(P["app_bottleneck"], o1)
+        x = self._residual("app_decoder_1_a", x, ops.as_nhwc(skips[-1]))
+        mu_0, z_0 = self._sampler("app_decoder_1_b", x)
+        x_ = ops.conv(P["app_decoder_1_c"], o2, z_0)
+        x = self._residual("app_decoder_1_d", x, x_)
+        x = self._upsample("app_decoder_1_e", x)
+        x = self._residual("app_decoder_2_a", x, None)
+        mu_1, z_1 = self._sampler("app_decoder_2_b", x)
+        return [mu_0, mu_1], [z_0, z_1]
+
+    def forward_dec_down(self, dec_up_outputs, skips: List[torch.Tensor], enc_down_mu=()):
+        self._ensure(dec_up_outputs[-1])
+        P = self._plans
+        mu, z = [], []
+        x = ops.conv(P["shape_bottleneck"], ops.as_nhwc(dec_up_outputs[-1]))
+        for blk in (1, 2):
+            skip_a = ops.as_nhwc(skips.pop())
+            skip_b = ops.as_nhwc(skips.pop())
+            m = None if len(enc_down_mu) == 0 else enc_down_mu[blk - 1]
+            x, mu_k, z_k = self._ar_block(f"shape_decoder_{blk}", x, skip_a, m)
+            mu.append(mu_k)
+            z.append(z_k)
+            x = self._nin(f"shape_decoder_{blk}_n", x, z_k)
+            x = self._residual(f"shape_decoder_{blk}_o", x, skip_b)
+            x = self._upsample(f"shape_decoder_{blk}_p", x)
+        names = ["shape_decoder_3", "shape_decoder_4", "shape_decoder_5"] + \
+                (["shape_decoder_5_a"] if self.vunet_256 else [])
+        for n in names:
+            skip_a = ops.as_nhwc(skips.pop())
+            skip_b = ops.as_nhwc(skips.pop())
+            x = self._up_block(n, x, skip_a, skip_b)
+        skip_a = ops.as_nhwc(skips.pop())
+        skip_b = ops.as_nhwc(skips.pop())
+        x = self._residual("shape_decoder_6.residual_0", x, skip_a)
+        x = self._residual("shape_decoder_6.residual_1", x, skip_b)
+        x = ops.conv(P["shape_decoder_6.conv"], x, nchw_out=True)
+        assert not skips
+        return x, mu, z
+
+    def forward(self, y_tilde, x=None, mean_mode="mean_appearance"):
+        want = 256 if self.vunet_256 else 128
+        assert y_tilde.shape[-1] == want
+        if x is not None:
+            assert x.shape[-1] == want
+        assert mean_mode in ["mean_appearance", "mean_shape"]
+        if mean_mode == "mean_appearance":
+            output_enc_up, skips_enc_up = self.forward_enc_up(x)
+            mu_app, z_app = self.forward_enc_down(output_enc_up, skips_enc_up)
+            output_dec_up, skips_dec_up = self.forward_dec_up(y_tilde)
+            x_tilde, mu_shape, z_shape = self.forward_dec_down(output_dec_up, skips_dec_up, z_app)
+            return x_tilde, mu_app, mu_shape
+        output_dec_up, skips_dec_up = self.forward_dec_up(y_tilde)
+        x_tilde, mu_shape, z_shape = self.forward_dec_down(output_dec_up, skips_dec_up)
+        return x_tilde

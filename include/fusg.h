@@ -1,0 +1,203 @@
+/*
+ * fusg.h - C ABI of libfusg.so: the MI355X (gfx950) kernels behind the per-vehicle novel-view
+ * synthesis hot path (stacked-hourglass -> Warp&Learn ICN -> VUnet -> EdgeConnect).
+ *
+ * The reference (alexj94/future_urban_scene_generation) has no FFI of its own: its hot path is
+ * Python nn.Module code that delegates every op to PyTorch.  The drop-in boundary
+ * is therefore the Python module surface (future_urban_scene_generation_amd/{stacked_hourglass,
+ * warp_learn,vunet,edgeconnect}); this header is the thin C layer those modules bind with ctypes.
+ * Each entry point names the reference op(s) it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  No torch types.  All pointers are DEVICE pointers
+ *    borrowed from the caller (e.g. tensor.data_ptr()); the library never allocates or frees
+ *    caller-visible memory and keeps no mutable global state besides the opt-in profiler.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call only enqueues
+ *    work on that stream; nothing synchronises, so calls are graph-capturable.
+ *  - Return 0 on success, negative fusg_status otherwise; fusg_last_error() gives a thread-local
+ *    message.  Shapes are validated on the host before any launch.
+ *  - Tensors are described by logical NCHW extents + element strides.  "NHWC-physical" means
+ *    sc == 1 (channels contiguous), sw = Cs, sh = W*Cs, sn = H*W*Cs with Cs >= c, Cs % 4 == 0 and a
+ *    16-byte aligned base: the layout every conv source must have.
+ */
+#ifndef FUSG_H
+#define FUSG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FUSG_VERSION 100
+
+typedef enum fusg_status {
+    FUSG_OK = 0,
+    FUSG_ERR_INVALID = -1,   /* bad shape / stride / enum            */
+    FUSG_ERR_LAUNCH = -2,    /* HIP launch or runtime error          */
+    FUSG_ERR_UNSUPPORTED = -3
+} fusg_status;
+
+typedef enum fusg_dtype { FUSG_F32 = 0, FUSG_U8 = 1, FUSG_I32 = 2 } fusg_dtype;
+
+typedef struct fusg_tensor {
+    void*   data;            /* device pointer, NULL = absent */
+    int64_t n, c, h, w;      /* logical NCHW extents          */
+    int64_t sn, sc, sh, sw;  /* strides in elements           */
+    int32_t dtype;           /* fusg_dtype                    */
+    int32_t _pad;
+} fusg_tensor;
+
+/* ---- convolution ------------------------------------------------------------------------- */
+
+typedef enum fusg_pad_mode { FUSG_PAD_ZERO = 0, FUSG_PAD_REFLECT = 1 } fusg_pad_mode;
+
+/* op applied to every in-bounds source element while the im2col tile is staged (padding stays 0) */
+typedef enum fusg_pre_op {
+    FUSG_PRE_NONE = 0,
+    FUSG_PRE_RELU = 1,
+    FUSG_PRE_ELU = 2,          /* vunet/layers.py:12-15 (Activation) applied before the conv    */
+    FUSG_PRE_AFFINE_RELU = 3,  /* relu(x*scale[b,c]+shift[b,c]): eval BatchNorm / InstanceNorm /
+                                  custom LayerNorm followed by ReLU, normalise-on-load          */
+    FUSG_PRE_AFFINE = 4
+} fusg_pre_op;
+
+typedef enum fusg_act {
+    FUSG_ACT_NONE = 0, FUSG_ACT_RELU = 1, FUSG_ACT_TANH = 2, FUSG_ACT_SIGMOID = 3,
+    FUSG_ACT_TANH01 = 4        /* (tanh(x)+1)/2, edgeconnect/networks.py:83 */
+} fusg_act;
+
+typedef enum fusg_store_mode {
+    FUSG_STORE_NORMAL = 0,
+    FUSG_STORE_D2S = 1,        /* DepthToSpace(2), DCR order, vunet/layers.py:173-196 */
+    FUSG_STORE_S2D = 2         /* SpaceToDepth(2), vunet/layers.py:199-221            */
+} fusg_store_mode;
+
+typedef enum fusg_tile {       /* workgroup tile (output pixels x output channels); 0 = auto */
+    FUSG_TILE_AUTO = 0, FUSG_TILE_128x128 = 1, FUSG_TILE_128x64 = 2, FUSG_TILE_128x32 = 3,
+    FUSG_TILE_64x64 = 4, FUSG_TILE_64x128 = 5
+} fusg_tile;
+
+/*
+ * One fused convolution launch.  Replaces, per call site, the reference's chains of
+ *   [torch.cat] -> [BatchNorm2d(eval)/InstanceNorm2d/LayerNorm -> ReLU | ELU] -> [ReflectionPad2d |
+ *   ZeroPad2d | nn.Upsample(2)] -> nn.Conv2d / nn.ConvTranspose2d(k4,s2,p1) -> [+bias] ->
+ *   [ReLU|tanh|sigmoid] -> [+residual] -> [DepthToSpace | SpaceToDepth]
+ * (stacked_hourglass/models.py:22-42; warp_learn/models.py:84-90,106-110,157-159;
+ *  vunet/layers.py:33-36,98-102,140-146; edgeconnect/networks.py:41-74,184-203).
+ *
+ * The GEMM view is  out[m, n] = sum_k A[m, k] * W[n, k],  m = (b, qy, qx) over the "q-space"
+ * output grid, k = (tap, concat-channel).  `ktab` (built at weight-pack time, see
+ * future_urban_scene_generation_amd/pack.py) has one int2 per 4 consecutive k:
+ *     .x = (dy & 0xffff) | (dx << 16)       input offset of the tap (includes -pad and dilation)
+ *     .y = channel offset in its source | src_select << 30 | invalid << 31
+ * so  A[m, k] = pre_op(src[b, qy*stride + dy, qx*stride + dx, ch])  with padding handled by
+ * `pad_mode` on the virtual (optionally 2x nearest-upsampled) input.  A transposed convolution
+ * is `nphase` = 4 phase-convolutions with their own tables/weights and output offsets.
+ */
+typedef struct fusg_conv_desc {
+    fusg_tensor src0;            /* NHWC-physical f32                                          */
+    fusg_tensor src1;            /* optional second source (channel concat), same n,h,w        */
+    fusg_tensor dst;             /* f32, any strides; logical extents of the FINAL output      */
+    fusg_tensor res0, res1;      /* optional residuals, same logical extents as dst            */
+    const float*   wpack;        /* [nphase][cout_pad][k_pad]                                  */
+    const float*   bias;         /* [cout_pad]                                                 */
+    const int32_t* ktab;         /* [nphase][k_pad/4][2]                                       */
+    const float*   pre_scale;    /* [B or 1][c0k + c1k] for the AFFINE pre-ops                 */
+    const float*   pre_shift;
+    int64_t        pre_bstride;  /* elements between batches in pre_scale/shift (0 = shared)   */
+    float*         workspace;    /* split-K partials: nphase*ksplit*M*cout_pad floats          */
+    int32_t k_pad;               /* multiple of 32                                             */
+    int32_t c0k;                 /* concat channels taken from src0 (multiple of 4)            */
+    int32_t cout, cout_pad;      /* cout_pad multiple of 32                                    */
+    int32_t stride;              /* q-space stride (1 or 2)                                    */
+    int32_t upsample;            /* 0/1: sources are read through a 2x nearest upsample        */
+    int32_t pad_mode;            /* fusg_pad_mode                                              */
+    int32_t pre_op;              /* fusg_pre_op                                                */
+    int32_t act;                 /* fusg_act                                                   */
+    int32_t store_mode;          /* fusg_store_mode                                            */
+    int32_t qh, qw;              /* q-space output grid                                        */
+    int32_t nphase;              /* 1, or 4 for ConvTranspose2d(k4,s2,p1)                      */
+    int32_t out_sy, out_sx;      /* dst y = qy*out_sy + out_oy[phase] (NORMAL store)           */
+    int32_t out_oy[4], out_ox[4];
+    int32_t dst_c_off;           /* write channels [dst_c_off, dst_c_off + cout') of dst       */
+    int32_t tile;                /* fusg_tile                                                  */
+    int32_t ksplit;              /* <=1: no split-K                                            */
+    int32_t _pad;
+} fusg_conv_desc;
+
+int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
+/* Heuristic used when tile == AUTO / to size the workspace: fills tile, ksplit and returns the
+ * workspace size in bytes (0 when ksplit <= 1). */
+int64_t fusg_conv2d_plan(fusg_conv_desc* d);
+
+/* ---- normalisation statistics -------------------------------------------------------------- */
+
+/* Per-(b, c) shifted sums over H*W in `nchunk` deterministic partials:
+ * partial[b][chunk][c] = { sum(x - p), sum((x - p)^2) },  p = x[b, 0, 0, c].   x NHWC-physical. */
+int fusg_chan_stats(const fusg_tensor* x, float* partial, int32_t nchunk, void* stream);
+/* nn.InstanceNorm2d(affine=False, eps) statistics (warp_learn/models.py:56; edgeconnect/
+ * networks.py:44): scale[b,c] = rstd, shift[b,c] = -mean*rstd (biased variance). */
+int fusg_in_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps,
+                     float* scale, float* shift, void* stream);
+/* Custom LayerNorm (warp_learn/models.py:26-35): per-sample mean and UNBIASED std over C*H*W,
+ * eps added to std: scale[b,c] = gamma[c]/(std+eps), shift[b,c] = beta[c] - mean*scale[b,c]. */
+int fusg_ln_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps,
+                     const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+
+/* ---- elementwise / data movement ------------------------------------------------------------ */
+
+/* dst = act(x*scale[b,c] + shift[b,c]) + res  (scale may be NULL: identity).  NHWC-physical.
+ * InstanceNorm apply + residual of ResBlock / ResnetBlock (warp_learn/models.py:106-110;
+ * edgeconnect/networks.py:198-199). */
+int fusg_affine_act(const fusg_tensor* x, const float* scale, const float* shift, int64_t bstride,
+                    int32_t act, const fusg_tensor* res, const fusg_tensor* dst, void* stream);
+/* F.max_pool2d(x, 2, stride=2) (stacked_hourglass/models.py:72,149).  NHWC-physical. */
+int fusg_maxpool2(const fusg_tensor* x, const fusg_tensor* dst, void* stream);
+/* dst = up1 + nearest_upsample2(low) (stacked_hourglass/models.py:81-82).  NHWC-physical. */
+int fusg_upsample2_add(const fusg_tensor* low, const fusg_tensor* up1, const fusg_tensor* dst, void* stream);
+/* Generic strided copy dst[b,c,y,x] = src[b,c,y,x]; channels [src.c, dst_c_fill) of dst are
+ * zero-filled (NCHW <-> NHWC conversion with channel padding at the module boundary). */
+int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32_t dst_c_fill, void* stream);
+/* dst = a + b with arbitrary strides (Sampler: mu + CPU-drawn noise, vunet/layers.py:166). */
+int fusg_add4d(const fusg_tensor* a, const fusg_tensor* b, const fusg_tensor* dst, void* stream);
+/* SpaceToDepth(2) / DepthToSpace(2), DCR order (vunet/layers.py:173-221). NHWC-physical; dst may
+ * be a channel slice of a wider buffer. */
+int fusg_space_to_depth2(const fusg_tensor* x, const fusg_tensor* dst, void* stream);
+int fusg_depth_to_space2(const fusg_tensor* x, const fusg_tensor* dst, void* stream);
+/* EdgeModel / InpaintingModel input assembly (edgeconnect/models.py:130-133, 236-238):
+ * mode 0: dst = cat(images*(1-m)+m, edges*(1-m), m)      images [B,1,H,W] -> dst [B,3(+pad),H,W]
+ * mode 1: dst = cat(images*(1-m)+m, edges)               images [B,3,H,W] -> dst [B,4,H,W]    */
+int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edges, const fusg_tensor* masks,
+                   const fusg_tensor* dst, int32_t mode, void* stream);
+/* Row-major first-occurrence argmax over H*W per (b, c) -> idx[b*C + c] = y*W + x (int32).
+ * Integer contract of get_maxima (utils/keypoint_utils.py:85-88). */
+int fusg_argmax_hw(const fusg_tensor* x, int32_t* idx, void* stream);
+/* to_image(from_LAB=False) quantiser (warp_learn/planes_utils.py:111-114):
+ * u8[b,y,x,c] = trunc(clip((x+1)/2*255, 0, 255)).  dst is a U8 tensor described as NCHW extents
+ * with HWC strides. */
+int fusg_to_image_u8(const fusg_tensor* x, const fusg_tensor* dst, void* stream);
+/* merged = out*m + img*(1-m); u8 = trunc(merged*255) (trajectory_inference.py:126-129). */
+int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_tensor* mask,
+                  const fusg_tensor* dst, void* stream);
+
+/* ---- misc ----------------------------------------------------------------------------------- */
+
+int         fusg_version(void);
+const char* fusg_last_error(void);
+const char* fusg_arch(void);                      /* "gfx950" */
+/* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their
+ * struct mirrors. */
+int         fusg_sizeof_tensor(void);
+int         fusg_sizeof_conv_desc(void);
+/* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+ * kind 0 = conv implicit-GEMM kernel.  Disabled by default; enabling makes launches record two
+ * events each.  fusg_prof_read synchronises the recorded events and returns totals since reset. */
+void fusg_prof_enable(int on);
+void fusg_prof_reset(void);
+int  fusg_prof_read(int kind, double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUSG_H */
