@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthesised 256x256 vehicle crops / second on N MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path over one batch of synthetic crops per rank:
+hourglass (+argmax) -> ICN -> VUnet first-frame (enc_up, enc_down, dec_up, dec_down) -> uint8
+quantisation [+ EdgeGenerator + InpaintGenerator with --inpaint], then (N > 1) the gather of the
+rendered uint8 crops to rank 0 over RCCL.  The default workload is BASELINE.json configs[1]:
+batch 32 of 256x256 crops per GPU, fp32 (the reference's dtype) on the fp32 matrix-core path.
+Inputs and weights are synthetic (no datasets / checkpoints in this environment) and resident in
+HBM before the timed region; VUnet's sampler noise is drawn on the CPU generator inside the step,
+as the reference does.  Weak scaling: each rank processes its own batch (vehicles are independent).
+
+Extra fields: "roofline" (conv implicit-GEMM kernel: algorithmic FLOPs of SURVEY.md §8d divided by
+the kernel's HIP-event time, measured live over the timed region on the launch stream) and
+"cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's
+cores on a bounded sample of the same workload; N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+# algorithmic conv FLOPs per crop at 256x256 (2*MAC, measured on the reference)
+GFLOP_PER_CROP = {"hg": 17.95, "icn": 130.12, "vunet_first": 76.27, "edge": 96.13, "inpaint": 97.37}
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="crops in the CPU baseline sample")
+    ap.add_argument("--no-prof", action="store_true", help="disable the per-launch HIP events (roofline leg)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from future_urban_scene_generation_amd import ops
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, synth_batch
+
+    torch.set_grad_enabled(False)
+    pipe = VehiclePipeline(dev, inpaint=args.inpaint)
+    batch = synth_batch(args.batch, args.res, dev, inpaint=args.inpaint, seed=rank)
+    n_total = args.batch * world
+    torch.manual_seed(1000 + rank)                      # per-rank noise stream
+
+    def step():
+        out = pipe.run(batch)
+        if world > 1:                                   # the path's only exchange: crops -> rank 0
+            crops = torch.cat([out["icn_u8"], out["vunet_u8"]], dim=-1)
+            gather_in_order(crops, n_total)
+            gather_in_order(out["kp_idx"], n_total)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = not args.no_prof
+    barrier()
+    if prof:
+        ops.prof_reset()
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if prof:
+        ops.prof_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    crops_per_s = n_total * args.steps / dt
+    scale = (args.res / 256.0) ** 2
+    gflop_crop = (GFLOP_PER_CROP["hg"] + GFLOP_PER_CROP["icn"] + GFLOP_PER_CROP["vunet_first"] +
+                  ((GFLOP_PER_CROP["edge"] + GFLOP_PER_CROP["inpaint"]) if args.inpaint else 0.0)) * scale
+
+    roofline = None
+    if prof:
+        conv_ms, conv_launches, _ = ops.prof_read(0)
+        alg_flops = gflop_crop * 1e9 * args.batch * args.steps          # this rank's conv work in the timed region
+        achieved = alg_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": "fusg::conv_igemm_f32 (all tile instantiations)",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": conv_launches // max(1, args.steps),
+                    "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
+                    "conv_ms_per_step": round(conv_ms / args.steps, 3),
+                    "alg_gflop_per_launch": round(gflop_crop * args.batch * args.steps / max(1, conv_launches), 3)}
+
+    cpu_baseline = None
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        from future_urban_scene_generation_amd.pipeline import load_schema
+        from future_urban_scene_generation_amd.synth import synth_state_dict
+        ns = max(1, min(args.cpu_sample, args.batch))
+        sds = {n: synth_state_dict(n, load_schema(n), 0)
+               for n in (("hg", "icn", "vunet") + (("edge", "inpaint") if args.inpaint else ()))}
+        cpu_batch = {k: v[:ns].cpu() for k, v in batch.items()}
+        oracle.crop_pass(sds, {k: v[:1] for k, v in cpu_batch.items()}, args.inpaint)        # warm-up
+        torch.manual_seed(77)
+        t1 = time.perf_counter()
+        ref = oracle.crop_pass(sds, cpu_batch, args.inpaint)
+        cpu_dt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(ns / cpu_dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(),
+                        "kind": "port", "sample": f"{ns} crops of the same workload (batch {ns}), 1 timed pass after warm-up"}
+        # quality of the GPU path on the very same sample and noise seed
+        torch.manual_seed(77)
+        got = pipe.run({k: v[:ns] for k, v in batch.items()})
+        import numpy as np
+        extra["ssim_vs_cpu_ref"] = round(min(oracle.ssim(got["icn_u8"].cpu().numpy(), ref["icn_u8"]),
+                                             oracle.ssim(got["vunet_u8"].cpu().numpy(), ref["vunet_u8"])), 6)
+        extra["kp_idx_exact"] = bool(np.array_equal(got["kp_idx"].cpu().numpy(), ref["kp_idx"]))
+
+    if rank == 0:
+        line = {"metric": "synthesised vehicle crops/sec @256x256", "value": round(crops_per_s, 3), "unit": "crops/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": ("configs[2]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
+                                        if args.inpaint else
+                                        "configs[1]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % args.batch,
+                           "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint),
+                           "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
+                "roofline": roofline, "cpu_baseline": cpu_baseline}
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Batched, shardable driver of the per-vehicle hot path (replaces the reference's vehicle-serial,
+batch-1 loop of trajectory_inference.py:55-250 for the network part).
+
+One *crop* = one first-frame pass for one vehicle:
+    hourglass heat-maps + argmax  ->  ICN completion  ->  VUnet enc_up/enc_down/dec_up/dec_down
+    [-> EdgeGenerator -> InpaintGenerator with ``inpaint=True``]
+Vehicles are independent, so a frame's vehicles are sharded contiguously over the
+ranks of one node with NO collective in the data path; the only exchange is the final gather of
+the rendered uint8 crops (and int32 keypoint indices) to rank 0, which pastes them in original
+vehicle order (later vehicles overwrite earlier ones, trajectory_inference.py:197-198).
+"""
+from __future__ import annotations
+
+import json
+import os
+from argparse import Namespace
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, size-balanced shard [lo, hi) of `n_items` vehicles for `rank` of `world`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0) -> Optional[torch.Tensor]:
+    """Gather per-rank shards ([n_local, ...], same trailing shape) to `dst` in vehicle order.
+    Works for any backend (RCCL on GPU tensors, gloo on CPU tensors).  Returns the full tensor on
+    `dst`, None elsewhere.  Shards may be ragged (n_items not a multiple of the world size)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_range(n_items, r, world) for r in range(world)]
+    max_n = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def load_schema(net: str):
+    with open(os.path.join(_REPO, "tests", "golden", f"schema_{net}.json")) as f:
+        raw = json.load(f, object_pairs_hook=OrderedDict)
+    return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
+
+
+class VehiclePipeline:
+    """Holds the five networks on one device and runs batches of crops through them."""
+
+    def __init__(self, device, inpaint: bool = False, state_dicts: Optional[Dict[str, dict]] = None, seed: int = 0):
+        from .edgeconnect.models import EdgeModel, InpaintingModel
+        from .stacked_hourglass.models import HourglassNet
+        from .synth import synth_state_dict
+        from .vunet.models import Vunet_fix_res
+        from .warp_learn.models import G_Resnet
+        self.device = torch.device(device)
+        self.inpaint = inpaint
+
+        def sd(net):
+            if state_dicts is not None and net in state_dicts:
+                return state_dicts[net]
+            return synth_state_dict(net, load_schema(net), seed)
+
+        self.hg = HourglassNet(num_stacks=2, num_blocks=1, num_classes=12)             # run_test.py:62
+        self.icn = G_Resnet(21)                                                         # run_test.py:74
+        self.vunet = Vunet_fix_res(Namespace(up_mode="subpixel", w_norm=True, drop_prob=0.2, vunet_256=True))
+        self.hg.load_state_dict(sd("hg"))
+        self.icn.load_state_dict(sd("icn"))
+        self.vunet.load_state_dict(sd("vunet"))
+        nets = [self.hg, self.icn, self.vunet]
+        if inpaint:
+            self.edge, self.inp = EdgeModel(None), InpaintingModel(None)
+            self.edge.generator.load_state_dict(sd("edge"))
+            self.inp.generator.load_state_dict(sd("inpaint"))
+            nets += [self.edge, self.inp]
+        for n in nets:
+            n.to(self.device).eval()
+
+    @torch.no_grad()
+    def run(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """batch: 'hg_x' [B,3,R,R], 'icn_x' [B,21,R,R], 'vu_x' [B,6,R,R], 'vu_y' [B,3,R,R]
+        (+ 'ec_img','ec_gray','ec_edge','ec_mask' with inpaint).  All device-resident.
+        Returns 'kp_idx' int32 [B,12], 'icn_u8' / 'vunet_u8' uint8 [B,R,R,3] (+ 'inpaint_u8')."""
+        from . import ops
+        out = {}
+        hm = self.hg(batch["hg_x"])["heatmaps"][-1]
+        out["kp_idx"] = ops.argmax_hw(hm)
+        out["icn_u8"] = ops.to_image_u8(self.icn(batch["icn_x"]))
+        vu = self.vunet
+        eo, es = vu.forward_enc_up(batch["vu_x"])                  # trajectory_inference.py:230-233
+        mu_app, _ = vu.forward_enc_down(eo, es)
+        do, ds = vu.forward_dec_up(batch["vu_y"])
+        xt, _, _ = vu.forward_dec_down(do, ds, mu_app)
+        out["vunet_u8"] = ops.to_image_u8(xt)
+        if self.inpaint:
+            e = self.edge(batch["ec_gray"], batch["ec_edge"], batch["ec_mask"])      # :124-129
+            p = self.inp(batch["ec_img"], e, batch["ec_mask"])
+            out["inpaint_u8"] = ops.merge_u8(p, batch["ec_img"], batch["ec_mask"])
+        return out
+
+
+def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic, device-resident inputs of the shapes/ranges the reference feeds."""
+    from .synth import synth_inputs
+    b = {"hg_x": synth_inputs("hg", batch, res, seed)["x"], "icn_x": synth_inputs("icn", batch, res, seed)["x"]}
+    v = synth_inputs("vunet", batch, res, seed)
+    b["vu_x"], b["vu_y"] = v["x"], v["y_tilde"]
+    if inpaint:
+        e = synth_inputs("edge", batch, res, seed)
+        b.update(ec_img=e["img"], ec_gray=e["gray"], ec_edge=e["edge"], ec_mask=e["mask"])
+    return {k: t.to(device) for k, t in b.items()}

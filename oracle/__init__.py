@@ -29,3 +29,4 @@ from .vunet import (vunet_enc_up, vunet_enc_down, vunet_dec_up, vunet_dec_down, 
 from .edgeconnect import (edge_generator_forward, inpaint_generator_forward,  # noqa: F401
                           edge_model_forward, inpaint_model_forward)
 from .host import to_image_u8, to_tensor_pm1, ssim                            # noqa: F401
+from .pipeline import crop_pass                                               # noqa: F401

@@ -183,4 +183,4 @@ def test_batch_consistency_icn():
     full = model("icn")(x)
     for b in range(3):
         one = model("icn")(x[b:b + 1])
-        assert _rel(one, full[b:b + 1].cpu()) < 1e-5
+        assert _rel(one, full[b:b + 1].cpu()) < 1e-4      # tile / chunk choices depend on B
