@@ -1,0 +1,356 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix
+// cores (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, 157 TFLOP/s dense peak).
+//
+// GEMM view: out[m, n] = sum_k A[m, k] * W[n, k];  m = (b, qy, qx) output pixels, n = output
+// channel, k = (tap, concat channel).  A is never materialised: a 256-thread workgroup gathers a
+// BM x 32 slice of it straight from the NHWC activations through the per-layer k-table (one int2
+// per 4 consecutive k: tap offset + channel offset + source select), applies the fused pre-op
+// (ReLU / ELU / per-(b,c) affine+ReLU = eval BatchNorm, InstanceNorm or LayerNorm normalise-on-
+// load), handles zero / reflect padding and the optional 2x nearest upsample in the address
+// computation, and stages it through LDS ([row][36] floats: conflict-free ds_read_b128 for the
+// MFMA operand fetch, conflict-free ds_write_b128 for the staging store).  The weight tile
+// ([cout][k], k contiguous, packed once at load time) is staged the same way.  Global loads for
+// step s+1 are issued before the MFMAs of step s (register double-buffering + two LDS buffers,
+// one barrier per K-step).  The epilogue adds the bias, applies the activation, adds up to two
+// residuals and stores through arbitrary destination strides with an optional DepthToSpace /
+// SpaceToDepth / transposed-convolution-phase coordinate mapping.  Small-M layers use split-K
+// with a deterministic slab reduction.
+//
+// Wave tiling: 4 waves as WM x WN, each wave owns TM x TN tiles of 32x32 (16 accumulator VGPRs
+// each).  MFMA operand maps (cdna_hip_programming.md §3): A lane l holds A[row l&31][k l>>5],
+// B lane l holds B[k l>>5][col l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+#pragma once
+#include "common.h"
+
+namespace fusg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;    // k per pipeline step
+constexpr int LDK = 36;   // LDS row pitch in floats (144 B): b128 reads and writes conflict-free
+
+struct ConvK {
+    const float* src0; const float* src1;
+    const float* wpack; const float* bias; const int2* ktab;
+    const float* pre_scale; const float* pre_shift;
+    float* dst; const float* res0; const float* res1; float* ws;
+    long dsn, dsc, dsh, dsw;
+    long r0n, r0c, r0h, r0w;
+    long r1n, r1c, r1h, r1w;
+    long pre_bstride;
+    int H, W, Hv, Wv, ups, Cs0, Cs1, C0;
+    int K_pad, nk, Cout, Cout_pad;
+    int stride, pad_mode, pre_op, act, store_mode;
+    int B, Ho, Wo, M, MT, NT;
+    int osy, osx, ooy[4], oox[4];
+    int dst_c_off, Cd;
+    int ksplit, steps_per_split;
+    int pre_relu;            // ReLU after the (optional) affine pre-op
+};
+
+enum { PK_NONE = 0, PK_ELU = 1, PK_AFFINE = 2 };   // compile-time pre-op kind
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case FUSG_ACT_RELU: return fmaxf(v, 0.f);
+        case FUSG_ACT_TANH: return tanhf(v);
+        case FUSG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case FUSG_ACT_TANH01: return (tanhf(v) + 1.f) / 2.f;
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+// Pixel part of the destination mapping: offsets (in elements) of logical channel 0 of output
+// pixel m in dst / res0 / res1.  Returns false for m >= M.
+struct PixOff { long d, r0, r1; };
+__device__ __forceinline__ bool pix_offsets(const ConvK& p, int phase, int m, PixOff& o) {
+    if (m >= p.M) return false;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    long Y, X, cq = 0;
+    if (p.store_mode == FUSG_STORE_D2S) { Y = 2 * oy; X = 2 * ox; }
+    else if (p.store_mode == FUSG_STORE_S2D) { Y = oy >> 1; X = ox >> 1; cq = (long)(((oy & 1) << 1) | (ox & 1)) * p.Cout; }
+    else { Y = (long)oy * p.osy + p.ooy[phase]; X = (long)ox * p.osx + p.oox[phase]; }
+    o.d = b * p.dsn + Y * p.dsh + X * p.dsw + (cq + p.dst_c_off) * p.dsc;
+    o.r0 = b * p.r0n + Y * p.r0h + X * p.r0w;
+    o.r1 = b * p.r1n + Y * p.r1h + X * p.r1w;
+    return true;
+}
+// Channel part.
+__device__ __forceinline__ void chan_offsets(const ConvK& p, int n, PixOff& o) {
+    if (p.store_mode == FUSG_STORE_D2S) {
+        const int q = n / p.Cd;
+        const int c = n - q * p.Cd;
+        o.d = (long)(q >> 1) * p.dsh + (long)(q & 1) * p.dsw + (long)c * p.dsc;
+        o.r0 = 0; o.r1 = 0;
+    } else {
+        o.d = (long)n * p.dsc; o.r0 = (long)n * p.r0c; o.r1 = (long)n * p.r1c;
+    }
+}
+__device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, const PixOff& co, float bias, float v) {
+    v = act_apply(v + bias, p.act);
+    if (p.res0) v += p.res0[po.r0 + co.r0];
+    if (p.res1) v += p.res1[po.r1 + co.r1];
+    p.dst[po.d + co.d] = v;
+}
+
+
+// TM x TN 32x32 tiles per wave, WM x WN waves; PK = pre-op kind; GEN = generic addressing
+// (reflect padding and/or fused 2x nearest upsample) vs the cheap zero-pad path.
+template <int TM, int TN, int WM, int WN, int PK, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int AP = BM / 32;   // staging passes for the A tile (32 rows x 8 float4 per pass)
+    constexpr int BP = BN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kc = t & 7;
+    const int r0 = t >> 3;
+
+    // XCD-aware tile order: consecutive tiles (same A rows, different N) stay on one XCD's L2.
+    int tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = tile % p.NT;
+    const int mt = tile / p.NT;
+    const int phase = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int hw = p.Ho * p.Wo;
+
+    // per-thread staging rows
+    int rb[AP], riy[AP], rix[AP];
+    long rowoff[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = mt * BM + r0 + 32 * i;
+        if (m < p.M) {
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wo;
+            rb[i] = b; riy[i] = oy * p.stride; rix[i] = (rem - oy * p.Wo) * p.stride;
+        } else { rb[i] = -1; riy[i] = 0; rix[i] = 0; }
+        rowoff[i] = rb[i] < 0 ? 0 : ((long)(rb[i] * p.H + riy[i]) * p.W + rix[i]);
+    }
+    // per-(b,c) affine parameters: one load per step when the whole tile lies in one sample
+    bool uni_b = true;
+    long aff_off = 0;
+    if (PK == PK_AFFINE && p.pre_bstride != 0) {
+        const int m_lo = mt * BM, m_hi = min(mt * BM + BM - 1, p.M - 1);
+        uni_b = (m_lo / hw) == (m_hi / hw);
+        aff_off = (long)(m_lo / hw) * p.pre_bstride;
+    }
+    const int2* ktab = p.ktab + (long)phase * (p.K_pad >> 2);
+    const float* wrow = p.wpack + ((long)phase * p.Cout_pad + (long)nt * BN + r0) * p.K_pad + kc * 4;
+
+    f32x4 areg[AP], breg[BP];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    unsigned okmask = 0;
+    int st_cidx = 0;
+
+    // ---- stage 1: address generation + global loads (raw values stay in registers)
+    int2 e_next = make_int2(0, (int)0x80000000);
+    auto issue = [&](int s, bool prefetch) {
+        const int2 e = e_next;                               // table entry fetched one step ahead
+        if (prefetch) e_next = ktab[(s + 1) * 8 + kc];
+        const int dy = (int)(short)(e.x & 0xffff);
+        const int dx = e.x >> 16;
+        const bool inval = e.y < 0;
+        const int src = (e.y >> 30) & 1;
+        const int coff = e.y & 0x3fffffff;
+        const float* base = src ? p.src1 : p.src0;
+        const int Cs = src ? p.Cs1 : p.Cs0;
+        st_cidx = coff + (src ? p.C0 : 0);
+        if (PK == PK_AFFINE && uni_b) {
+            sc = *(const f32x4*)(p.pre_scale + aff_off + st_cidx);
+            sh = *(const f32x4*)(p.pre_shift + aff_off + st_cidx);
+        }
+        const long tapoff = (long)(dy * p.W + dx) * Cs + coff;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            int iy = riy[i] + dy, ix = rix[i] + dx;
+            bool ok = rb[i] >= 0 && !inval;
+            long off;
+            if (GEN) {
+                if (p.pad_mode == FUSG_PAD_REFLECT) {
+                    iy = iy < 0 ? -iy : (iy >= p.Hv ? 2 * p.Hv - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= p.Wv ? 2 * p.Wv - 2 - ix : ix);
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+                }
+                iy >>= p.ups; ix >>= p.ups;
+                off = ((long)(rb[i] * p.H + iy) * p.W + ix) * Cs + coff;
+            } else {
+                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                off = rowoff[i] * Cs + tapoff;
+            }
+            off = ok ? off : 0;                              // branch-free: always a valid address
+            areg[i] = *(const f32x4*)(base + off);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) breg[i] = *(const f32x4*)(wrow + (long)(32 * i) * p.K_pad + s * BK);
+    };
+    // ---- stage 2 (after the MFMAs of the current step): pre-op, zero the padding, write LDS
+    auto commit = [&](int buf) {
+        float* a = As + buf * BM * LDK + r0 * LDK + kc * 4;
+        float* b = Bs + buf * BN * LDK + r0 * LDK + kc * 4;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            f32x4 v = areg[i];
+            if (PK == PK_ELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
+            } else if (PK == PK_AFFINE) {
+                if (!uni_b) {
+                    const long o = (long)max(rb[i], 0) * p.pre_bstride + st_cidx;
+                    sc = *(const f32x4*)(p.pre_scale + o);
+                    sh = *(const f32x4*)(p.pre_shift + o);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc[c], sh[c]);
+            }
+            if (PK != PK_ELU && p.pre_relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+            const bool ok = (okmask >> i) & 1u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
+            *(f32x4*)(a + 32 * i * LDK) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *(f32x4*)(b + 32 * i * LDK) = breg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int s_begin = ks * p.steps_per_split;
+    const int s_end = min(p.nk, s_begin + p.steps_per_split);
+
+    if (s_begin < s_end) {
+        e_next = ktab[s_begin * 8 + kc];
+        issue(s_begin, s_begin + 1 < s_end);
+        commit(0);
+        __syncthreads();
+        const int a_off = (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+        const int b_off = (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            const bool more = s + 1 < s_end;
+            if (more) issue(s + 1, s + 2 < s_end);
+            const float* Ab = As + buf * BM * LDK + a_off;
+            const float* Bb = Bs + buf * BN * LDK + b_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDK + j * 8);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) b[i] = *(const f32x4*)(Bb + i * 32 * LDK + j * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[jj][e], acc[i][jj], 0, 0, 0);
+            }
+            if (more) commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    const int mrow0 = mt * BM + wm * TM * 32 + 4 * (lane >> 5);
+    if (p.ksplit > 1) {
+        float* ws = p.ws + ((long)(phase * p.ksplit + ks) * p.M) * p.Cout_pad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ws[(long)m * p.Cout_pad + ncol0 + j * 32] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    PixOff co[TN];
+    float bias[TN];
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        nok[j] = n < p.Cout;
+        bias[j] = p.bias[n];
+        chan_offsets(p, n, co[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            PixOff po;
+            if (pix_offsets(p, phase, m, po)) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+            }
+        }
+}
+
+// one launcher per tile shape; instantiated in conv_tile_*.hip (separate TUs for parallel builds)
+template <int TM, int TN, int WM, int WN>
+hipError_t launch_tile(const ConvK& k, dim3 grid, hipStream_t s, int pk, bool gen) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    const void* fn = nullptr;
+#define FUSG_PICK(PKV, GENV) fn = (const void*)conv_igemm_f32<TM, TN, WM, WN, PKV, GENV>
+    if (pk == PK_NONE) { if (gen) FUSG_PICK(PK_NONE, true); else FUSG_PICK(PK_NONE, false); }
+    else if (pk == PK_ELU) { if (gen) FUSG_PICK(PK_ELU, true); else FUSG_PICK(PK_ELU, false); }
+    else { if (gen) FUSG_PICK(PK_AFFINE, true); else FUSG_PICK(PK_AFFINE, false); }
+#undef FUSG_PICK
+    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+    if (!attr_done[pk][gen ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[pk][gen ? 1 : 0] = true;
+    }
+    ConvK kk = k;
+    void* args[] = {(void*)&kk};
+    return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
+}
+
+hipError_t launch_tile_128x128(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_tile_128x64(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_tile_128x32(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_tile_64x64(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_tile_64x128(const ConvK&, dim3, hipStream_t, int, bool);
+
+}  // namespace fusg
