@@ -65,6 +65,7 @@ _SIGS = {
     "fusg_space_to_depth2": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_depth_to_space2": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_ec_inputs": (C.c_int, [_TP, _TP, _TP, _TP, C.c_int32, C.c_void_p]),
+    "fusg_hshift_sum": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _TP, C.c_void_p]),
     "fusg_argmax_hw": (C.c_int, [_TP, C.c_void_p, C.c_void_p]),
     "fusg_to_image_u8": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_merge_u8": (C.c_int, [_TP, _TP, _TP, _TP, C.c_void_p]),

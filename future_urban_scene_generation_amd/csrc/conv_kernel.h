@@ -61,7 +61,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+// ELU(alpha=1) as ATen computes it on CPU: x > 0 ? x : exp(x) - 1 (v_exp_f32 based; abs error ~1e-7)
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
 // Pixel part of the destination mapping: offsets (in elements) of logical channel 0 of output
 // pixel m in dst / res0 / res1.  Returns false for m >= M.

@@ -159,6 +159,29 @@ __global__ __launch_bounds__(256) void ec_inputs_kernel(T4 img, T4 edg, T4 msk, 
     }
 }
 
+// row-split conv, horizontal gather-sum: one thread per output pixel; t is [B,H,W,Cs] with cout*kw channels
+__global__ __launch_bounds__(256) void hshift_sum_kernel(const float* __restrict__ t, int tCs, const float* __restrict__ bias,
+                                                         int kw, int pad, int reflect, int act, T4 d, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int W = (int)d.w;
+    const int x = (int)(i % W);
+    const long row = i / W;                       // b*H + y
+    const long y = row % d.h, b = row / d.h;
+    float* dp = (float*)d.p + b * d.sn + y * d.sh + (long)x * d.sw;
+    for (int co = 0; co < (int)d.c; ++co) {
+        float acc = bias[co];
+        for (int kx = 0; kx < kw; ++kx) {
+            int xx = x + kx - pad;
+            bool ok = true;
+            if (reflect) xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+            else ok = (unsigned)xx < (unsigned)W;
+            if (ok) acc += t[(row * W + xx) * tCs + co * kw + kx];
+        }
+        dp[co * d.sc] = act1(acc, act);
+    }
+}
+
 // first-occurrence argmax over H*W; one block per (b, c)
 __global__ __launch_bounds__(256) void argmax_hw_kernel(T4 x, int* __restrict__ idx) {
     __shared__ float sv[256];
@@ -319,6 +342,18 @@ extern "C" int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edge
     hipLaunchKernelGGL(ec_inputs_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, view(*images), view(*edges),
                        view(*masks), view(*dst), mode, total);
     FUSG_LAUNCH_CHECK("ec_inputs");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t kw, int32_t pad, int32_t pad_mode, int32_t act,
+                               const fusg_tensor* dst, void* stream) {
+    FUSG_CHECK(t && dst && bias && is_nhwc(*t) && dst->data && dst->dtype == FUSG_F32 && same_nhw(*t, *dst), "hshift_sum: tensors");
+    FUSG_CHECK(kw >= 1 && kw <= 15 && pad >= 0 && pad < dst->w && dst->c * kw <= t->c, "hshift_sum: kw %d pad %d cout %ld tc %ld", kw, pad, (long)dst->c, (long)t->c);
+    FUSG_CHECK(act >= 0 && act <= FUSG_ACT_TANH01 && (pad_mode == 0 || pad_mode == 1), "hshift_sum: act/pad_mode");
+    const long total = dst->n * dst->h * dst->w;
+    hipLaunchKernelGGL(hshift_sum_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)t->data,
+                       (int)t->sw, bias, kw, pad, pad_mode, act, view(*dst), total);
+    FUSG_LAUNCH_CHECK("hshift_sum");
     return FUSG_OK;
 }
 

@@ -81,7 +81,7 @@ class _Generator(FusedNet):
              "mid": [],
              "up1": pack.pack_conv_transpose_k4s2p1(*self._wb(d[0])).to(device),
              "up2": pack.pack_conv_transpose_k4s2p1(*self._wb(d[3])).to(device),
-             "head": pack.pack_conv(*self._wb(d[7]), pad=3, pad_mode=L.PAD_REFLECT).to(device)}
+             "head": pack.pack_conv_rowsplit(*self._wb(d[7]), pad=3, pad_mode=L.PAD_REFLECT).to(device)}
         for blk in self.middle:
             dl = blk.dilation
             P["mid"].append((pack.pack_conv(*self._wb(blk.conv_block[1]), pad=dl, dil=dl, pad_mode=L.PAD_REFLECT).to(device),
@@ -109,7 +109,7 @@ class _Generator(FusedNet):
         st = ops.instnorm_stats(c)
         c = ops.conv(P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         st = ops.instnorm_stats(c)
-        return ops.conv(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act, nchw_out=True)
+        return ops.conv_rowsplit(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._ensure(x)

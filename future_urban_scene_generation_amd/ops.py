@@ -173,6 +173,19 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     return out
 
 
+def conv_rowsplit(plan: ConvPlan, x0: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
+                  act: int = L.ACT_NONE, nchw_out: bool = True) -> torch.Tensor:
+    """Small-cout head (pack.pack_conv_rowsplit): kh x 1 implicit GEMM + horizontal gather-sum."""
+    rs = plan.rowsplit
+    t = conv(plan, x0, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride)
+    b, _, h, w = t.shape
+    out = torch.empty((b, rs["cout"], h, w), device=x0.device, dtype=torch.float32) if nchw_out \
+        else nhwc_empty(b, rs["cout"], h, w, x0.device)
+    L.check(L.lib().fusg_hshift_sum(C.byref(desc(t)), plan.dev["rs_bias"].data_ptr(), rs["kw"], rs["pad"], plan.pad_mode,
+                                    int(act), C.byref(desc(out)), stream_ptr()), "hshift_sum")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # normalisation
 # ---------------------------------------------------------------------------------------------

@@ -43,6 +43,8 @@ class ConvPlan:
     upsample: int = 0
     nphase: int = 1                # 4 = ConvTranspose2d(k4, s2, p1)
     flops_per_pixel: float = 0.0   # algorithmic 2*MAC per q-space output pixel (all phases: per input pixel)
+    pad_w: int = -1                # horizontal padding when it differs from `pad` (row-split heads: 0)
+    rowsplit: Optional[dict] = None
     dev: dict = field(default_factory=dict)
 
     def to(self, device) -> "ConvPlan":
@@ -52,6 +54,8 @@ class ConvPlan:
                         "wpack": self.wpack.to(device).contiguous(),
                         "bias": self.bias.to(device).contiguous(),
                         "ktab": self.ktab.to(device).contiguous()}
+            if self.rowsplit is not None:
+                self.dev["rs_bias"] = self.rowsplit["bias"].to(device).contiguous()
         return self
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
@@ -59,8 +63,9 @@ class ConvPlan:
         if self.nphase == 4:
             return h, w
         hv, wv = h << self.upsample, w << self.upsample
+        pw = self.pad if self.pad_w < 0 else self.pad_w
         return ((hv + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1,
-                (wv + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1)
+                (wv + 2 * pw - self.dil * (self.kw - 1) - 1) // self.stride + 1)
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):
@@ -139,6 +144,26 @@ def pack_conv_transpose_k4s2p1(weight: torch.Tensor, bias: Optional[torch.Tensor
     return ConvPlan(wpack=torch.stack(panels).contiguous(), bias=b, ktab=torch.stack(tabs).contiguous(), cout=cout,
                     cout_pad=cout_pad, k_pad=k_pad, c_split=(cin,), c0k=c0k, c1k=c1k, kh=4, kw=4, stride=1, pad=0, dil=1,
                     pad_mode=0, upsample=0, nphase=4, flops_per_pixel=2.0 * cout * cin * 16)
+
+
+def pack_conv_rowsplit(weight: torch.Tensor, bias: Optional[torch.Tensor], *, pad: int, pad_mode: int = 0) -> ConvPlan:
+    """Small-cout kh x kw convolution as a kh x 1 implicit GEMM with cout*kw (<= 32) output columns:
+    t[., co*kw + kx] = sum_{ky, c} in[y + ky - pad, x, c] * w[co, c, ky, kx]; the horizontal taps are
+    summed afterwards by fusg_hshift_sum (which also adds the bias and applies the activation).
+    Cuts the MFMA work of the 7x7 -> 3 / 1 channel heads by kw (the N tile is 32 wide either way)."""
+    w = weight.detach().to("cpu", torch.float32)
+    cout, cin, kh, kw = w.shape
+    assert cout * kw <= 32, (cout, kw)
+    w2 = w.permute(0, 3, 1, 2).reshape(cout * kw, cin, kh, 1)        # [co*kw + kx, c, ky, 0]
+    taps = [(ky, 0, ky - pad, 0) for ky in range(kh)]
+    panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(w2, taps, (cin,))
+    plan = ConvPlan(wpack=panel[None].contiguous(), bias=torch.zeros(cout_pad), ktab=tab[None].contiguous(),
+                    cout=cout * kw, cout_pad=cout_pad, k_pad=k_pad, c_split=(cin,), c0k=c0k, c1k=c1k, kh=kh, kw=1,
+                    stride=1, pad=pad, dil=1, pad_mode=pad_mode, upsample=0, nphase=1,
+                    flops_per_pixel=2.0 * cout * cin * kh * kw, pad_w=0)
+    plan.rowsplit = {"kw": kw, "pad": pad, "cout": cout,
+                     "bias": torch.zeros(cout) if bias is None else bias.detach().to("cpu", torch.float32).clone()}
+    return plan
 
 
 # ---- parameter folds (pure functions of the parameters; exact formulas of the reference's wrappers) ----

@@ -106,6 +106,12 @@ class G_Resnet(FusedNet):
                               pad_mode=L.PAD_REFLECT if blk.pad_type == "reflect" else L.PAD_ZERO,
                               upsample=upsample).to(device)
 
+    def _pack_head(self, blk: Conv2dBlock, device):
+        """7x7 -> output_nc head: row-split form when output_nc*7 fits one 32-wide N tile."""
+        if blk.conv.cout * blk.kernel_size <= 32 and blk.pad_type == "reflect":
+            return pack.pack_conv_rowsplit(blk.conv.weight, blk.conv.bias, pad=blk.padding, pad_mode=L.PAD_REFLECT).to(device)
+        return self._pack_block(blk, device)
+
     def _pack_res(self, rbs: ResBlocks, device) -> List[tuple]:
         return [(self._pack_block(rb.model[0], device), self._pack_block(rb.model[1], device)) for rb in rbs.model]
 
@@ -117,7 +123,7 @@ class G_Resnet(FusedNet):
              "enc_res": self._pack_res(enc[1 + nd], device),
              "dec_res": self._pack_res(dec[0], device),
              "up": [], "ln": [],
-             "head": self._pack_block(dec[1 + 2 * nd], device)}
+             "head": self._pack_head(dec[1 + 2 * nd], device)}
         for i in range(nd):
             blk = dec[2 + 2 * i]
             P["up"].append(self._pack_block(blk, device, upsample=1))
@@ -151,6 +157,8 @@ class G_Resnet(FusedNet):
             y = ops.conv(p, y, pre_op=pre_op, pre=pre, pre_bstride=bs)
             pre = ops.layernorm_stats(y, gamma, beta, eps)
             pre_op, bs = L.PRE_AFFINE_RELU, y.shape[1]
+        if P["head"].rowsplit is not None:
+            return ops.conv_rowsplit(P["head"], y, pre_op=pre_op, pre=pre, pre_bstride=bs, act=L.ACT_TANH)
         return ops.conv(P["head"], y, pre_op=pre_op, pre=pre, pre_bstride=bs, act=L.ACT_TANH, nchw_out=True)
 
     def decode(self, content: torch.Tensor) -> torch.Tensor:

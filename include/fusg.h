@@ -170,6 +170,14 @@ int fusg_depth_to_space2(const fusg_tensor* x, const fusg_tensor* dst, void* str
  * mode 1: dst = cat(images*(1-m)+m, edges)               images [B,3,H,W] -> dst [B,4,H,W]    */
 int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edges, const fusg_tensor* masks,
                    const fusg_tensor* dst, int32_t mode, void* stream);
+/* Second half of the "row-split" small-Cout convolution: a kh x kw conv with cout*kw <= 32 is run
+ * as a kh x 1 implicit GEMM producing t[b, co*kw + kx, y, x] = sum_{ky,c} in[y+ky-pad, x, c]*w[co,c,ky,kx]
+ * (kw x fewer MFMA flops than padding cout to 32), then
+ *   dst[b, co, y, x] = act(bias[co] + sum_kx t[b, co*kw + kx, y, pad_x(x + kx - pad)])
+ * with zero / reflect handling of the horizontal border.  t NHWC-physical, dst any strides.
+ * Used for the 7x7 heads (warp_learn/models.py:182-183; edgeconnect/networks.py:72-73,123-124). */
+int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t kw, int32_t pad, int32_t pad_mode,
+                    int32_t act, const fusg_tensor* dst, void* stream);
 /* Row-major first-occurrence argmax over H*W per (b, c) -> idx[b*C + c] = y*W + x (int32).
  * Integer contract of get_maxima (utils/keypoint_utils.py:85-88). */
 int fusg_argmax_hw(const fusg_tensor* x, int32_t* idx, void* stream);

@@ -228,3 +228,17 @@ def test_ec_inputs():
     _close(e, torch.cat((gray * (1 - m) + m, edge * (1 - m), m), 1), 0, 0)
     p = ops.ec_inputs(img.to(dev()), edge.to(dev()), m.to(dev()), 1)
     _close(p, torch.cat((img * (1 - m) + m, edge), 1), 0, 0)
+
+
+@pytest.mark.parametrize("cout,act,fn", [(3, L.ACT_TANH, torch.tanh), (1, L.ACT_SIGMOID, torch.sigmoid)])
+def test_rowsplit_head(cout, act, fn):
+    x = _rand(2, 64, 24, 20, seed=1)
+    w = _rand(cout, 64, 7, 7, seed=2, scale=0.02)
+    b = _rand(cout, seed=3)
+    sc, sh = _rand(2, 64, seed=4), _rand(2, 64, seed=5)
+    plan = pack.pack_conv_rowsplit(w, b, pad=3, pad_mode=1)
+    y = F.relu(x * sc.view(2, 64, 1, 1) + sh.view(2, 64, 1, 1))
+    ref = fn(F.conv2d(F.pad(y, (3,) * 4, mode="reflect"), w, b))
+    got = ops.conv_rowsplit(plan, _nhwc(x), pre_op=L.PRE_AFFINE_RELU, pre=(sc.to(dev()), sh.to(dev())), pre_bstride=64, act=act)
+    assert got.is_contiguous()
+    _close(got, ref)

@@ -100,3 +100,23 @@ def test_folds():
         vv = F.normalize(_rand(wo.numel() // n_u, seed=12), dim=0)
         wm = wo.permute(1, 0, 2, 3).reshape(7, -1) if tr else wo.reshape(5, -1)
         torch.testing.assert_close(pack.fold_spectral_norm(wo, u, vv, tr), wo / torch.dot(u, wm.mv(vv)))
+
+
+def test_rowsplit_head_matches_conv():
+    """kh x 1 GEMM + horizontal gather-sum == the full 7x7 reflect conv (small-cout heads)."""
+    x = _rand(2, 8, 9, 10, seed=1)
+    w = _rand(3, 8, 7, 7, seed=2) * 0.1
+    b = _rand(3, seed=3)
+    plan = pack.pack_conv_rowsplit(w, b, pad=3, pad_mode=1)
+    t = assemble_normal(plan, emulate_conv(plan, x))                  # [B, 21, H, W]
+    assert t.shape == (2, 21, 9, 10)
+    W = 10
+    out = torch.zeros(2, 3, 9, 10) + b.view(1, 3, 1, 1)
+    for co in range(3):
+        for kx in range(7):
+            for xo in range(W):
+                xx = xo + kx - 3
+                xx = -xx if xx < 0 else (2 * W - 2 - xx if xx >= W else xx)
+                out[:, co, :, xo] += t[:, co * 7 + kx, :, xx]
+    ref = F.conv2d(F.pad(x, (3,) * 4, mode="reflect"), w, b)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
