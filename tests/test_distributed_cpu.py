@@ -1,0 +1,76 @@
+"""CPU, gloo, world_size 2 and 3: the sharding + ordered-gather logic of the multi-GPU path
+(pipeline.shard_range / gather_in_order).  The per-rank compute is replaced by a deterministic
+stand-in render (the HIP modules have no CPU fallback); what is tested is that rank 0 receives every
+vehicle's crop exactly once, in original vehicle order, for even and ragged shard sizes."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from future_urban_scene_generation_amd.pipeline import gather_in_order, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_render(vehicle_ids):
+    """Stand-in for VehiclePipeline.run: a uint8 'crop' that encodes the global vehicle index."""
+    out = torch.zeros((len(vehicle_ids), 4, 4, 3), dtype=torch.uint8)
+    for i, v in enumerate(vehicle_ids):
+        out[i] = (v * 3 + torch.arange(48).reshape(4, 4, 3)) % 251
+    return out
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n_items, rank, world)
+        local = _fake_render(list(range(lo, hi)))
+        full = gather_in_order(local, n_items)
+        kp = gather_in_order(torch.arange(lo, hi, dtype=torch.int32).view(-1, 1).repeat(1, 12), n_items)
+        if rank == 0:
+            q.put((full.clone(), kp.clone()))
+        else:
+            assert full is None and kp is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 8), (2, 7), (3, 10)])
+def test_gather_in_vehicle_order(world, n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, kp = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(full, _fake_render(list(range(n_items))))          # == the single-process result
+    assert torch.equal(kp[:, 0], torch.arange(n_items, dtype=torch.int32))
+
+
+def test_single_process_is_identity():
+    x = _fake_render([0, 1, 2])
+    assert gather_in_order(x, 3) is x
