@@ -38,7 +38,8 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("act", C.c_int32), ("store_mode", C.c_int32), ("qh", C.c_int32), ("qw", C.c_int32),
                 ("nphase", C.c_int32), ("out_sy", C.c_int32), ("out_sx", C.c_int32),
                 ("out_oy", C.c_int32 * 4), ("out_ox", C.c_int32 * 4),
-                ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("_pad", C.c_int32)]
+                ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
+                ("wpack_h", C.c_void_p)]
 
 
 # enums (include/fusg.h)
@@ -47,6 +48,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PRE_NONE, PRE_RELU, PRE_ELU, PRE_AFFINE_RELU, PRE_AFFINE = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_TANH01 = 0, 1, 2, 3, 4
 STORE_NORMAL, STORE_D2S, STORE_S2D = 0, 1, 2
+PREC_F32, PREC_F16X3 = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4, 5
 
 _TP = C.POINTER(Tensor)

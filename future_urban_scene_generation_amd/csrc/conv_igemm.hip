@@ -81,7 +81,10 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     if (has1) {
         FUSG_CHECK(is_nhwc(d->src1) && same_nhw(x0, d->src1), "conv2d: src1 must be NHWC-physical with src0's n,h,w");
     }
-    FUSG_CHECK(d->wpack && d->bias && d->ktab, "conv2d: wpack/bias/ktab missing");
+    FUSG_CHECK(d->bias && d->ktab, "conv2d: bias/ktab missing");
+    FUSG_CHECK(d->precision == FUSG_PREC_F32 || d->precision == FUSG_PREC_F16X3, "conv2d: precision %d", d->precision);
+    if (d->precision == FUSG_PREC_F32) FUSG_CHECK(d->wpack, "conv2d: wpack missing");
+    else FUSG_CHECK(d->wpack_h && (((uintptr_t)d->wpack_h) & 15) == 0, "conv2d: F16X3 needs a 16B-aligned wpack_h");
     FUSG_CHECK((((uintptr_t)d->wpack) & 15) == 0 && (((uintptr_t)d->ktab) & 7) == 0, "conv2d: wpack/ktab misaligned");
     FUSG_CHECK(d->k_pad > 0 && d->k_pad % BK == 0, "conv2d: k_pad %d not a positive multiple of %d", d->k_pad, BK);
     FUSG_CHECK(d->cout > 0 && d->cout_pad % 32 == 0 && d->cout <= d->cout_pad, "conv2d: bad cout %d / cout_pad %d", d->cout, d->cout_pad);
@@ -146,6 +149,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     if (d->res0.data) { k.res0 = (const float*)d->res0.data; k.r0n = d->res0.sn; k.r0c = d->res0.sc; k.r0h = d->res0.sh; k.r0w = d->res0.sw; }
     if (d->res1.data) { k.res1 = (const float*)d->res1.data; k.r1n = d->res1.sn; k.r1c = d->res1.sc; k.r1h = d->res1.sh; k.r1w = d->res1.sw; }
     k.ws = d->workspace;
+    k.wpack_h = (const _Float16*)d->wpack_h;
     k.H = (int)x0.h; k.W = (int)x0.w; k.ups = d->upsample; k.Hv = k.H << k.ups; k.Wv = k.W << k.ups;
     k.Cs0 = (int)x0.sw; k.Cs1 = has1 ? (int)d->src1.sw : (int)x0.sw; k.C0 = d->c0k;
     k.K_pad = d->k_pad; k.nk = d->k_pad / BK; k.Cout = d->cout; k.Cout_pad = d->cout_pad;
@@ -171,6 +175,15 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         default: break;
     }
     const bool gen = d->pad_mode == FUSG_PAD_REFLECT || d->upsample != 0;
+    if (d->precision == FUSG_PREC_F16X3) {
+        switch (d->tile) {
+            case FUSG_TILE_128x128: e = launch_h3_128x128(k, grid, s, pk, gen); break;
+            case FUSG_TILE_128x64:  e = launch_h3_128x64(k, grid, s, pk, gen); break;
+            case FUSG_TILE_128x32:  e = launch_h3_128x32(k, grid, s, pk, gen); break;
+            case FUSG_TILE_64x64:   e = launch_h3_64x64(k, grid, s, pk, gen); break;
+            default:                e = launch_h3_64x128(k, grid, s, pk, gen); break;
+        }
+    } else
     switch (d->tile) {
         case FUSG_TILE_128x128: e = launch_tile_128x128(k, grid, s, pk, gen); break;
         case FUSG_TILE_128x64:  e = launch_tile_128x64(k, grid, s, pk, gen); break;

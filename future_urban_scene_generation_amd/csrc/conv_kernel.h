@@ -47,6 +47,7 @@ struct ConvK {
     int dst_c_off, Cd;
     int ksplit, steps_per_split;
     int pre_relu;            // ReLU after the (optional) affine pre-op
+    const _Float16* wpack_h; // f16x3 path: [nphase][2 (hi, lo*2^11)][cout_pad][k_pad] halves
 };
 
 enum { PK_NONE = 0, PK_ELU = 1, PK_AFFINE = 2 };   // compile-time pre-op kind
@@ -353,5 +354,10 @@ hipError_t launch_tile_128x64(const ConvK&, dim3, hipStream_t, int, bool);
 hipError_t launch_tile_128x32(const ConvK&, dim3, hipStream_t, int, bool);
 hipError_t launch_tile_64x64(const ConvK&, dim3, hipStream_t, int, bool);
 hipError_t launch_tile_64x128(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_h3_128x128(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_h3_128x64(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_h3_128x32(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_h3_64x64(const ConvK&, dim3, hipStream_t, int, bool);
+hipError_t launch_h3_64x128(const ConvK&, dim3, hipStream_t, int, bool);
 
 }  // namespace fusg

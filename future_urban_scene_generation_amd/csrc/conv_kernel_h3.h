@@ -1,0 +1,313 @@
+// Split-precision variant of the fused implicit-GEMM convolution (gfx950): fp32 operands are split
+// on the fly into fp16 (hi, lo*2^11) pairs and multiplied on the fp16 matrix cores
+// (v_mfma_f32_32x32x16_f16, fp32 accumulate) as  a*w ~= ah*wh + (ah*wl + al*wh) / 2^11.
+// fp16 x fp16 products are exact in fp32 (11+11 significant bits), the scaled lo parts keep 11 more
+// bits of each operand without touching fp16 denormals, and the cross terms accumulate in a second
+// fp32 accumulator that is folded in once in the epilogue - so the result carries ~2^-22 relative
+// error per product (fp32 MFMA: 2^-24) at 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less
+// matrix-pipe time.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
+// LDS: four fp16 tiles per buffer ([row][40 halves], 80-byte pitch: conflict-free ds_read_b128).
+#pragma once
+#include "conv_kernel.h"
+
+namespace fusg {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDH = 40;                 // LDS row pitch in halves
+constexpr float H3_SCALE = 2048.f;      // 2^11
+
+__device__ __forceinline__ void split4(const f32x4 v, h4& hi, h4& lo) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = fminf(fmaxf(v[c], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)a;
+        hi[c] = h;
+        lo[c] = (_Float16)((a - (float)h) * H3_SCALE);
+    }
+}
+
+template <int TM, int TN, int WM, int WN, int PK, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int AP = BM / 32;
+    constexpr int BCH = BN * 4;                    // 16-byte chunks in one fp16 weight tile (BN x 32 halves)
+    constexpr int BPL = (BCH + 255) / 256;         // chunks per thread
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    _Float16* Ah = smem_h;                         // [2][BM][LDH]
+    _Float16* Al = Ah + 2 * BM * LDH;
+    _Float16* Bh = Al + 2 * BM * LDH;              // [2][BN][LDH]
+    _Float16* Bl = Bh + 2 * BN * LDH;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kc = t & 7;
+    const int r0 = t >> 3;
+
+    int tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = tile % p.NT;
+    const int mt = tile / p.NT;
+    const int phase = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int hw = p.Ho * p.Wo;
+
+    int rb[AP], riy[AP], rix[AP];
+    long rowoff[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = mt * BM + r0 + 32 * i;
+        if (m < p.M) {
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.Wo;
+            rb[i] = b; riy[i] = oy * p.stride; rix[i] = (rem - oy * p.Wo) * p.stride;
+        } else { rb[i] = -1; riy[i] = 0; rix[i] = 0; }
+        rowoff[i] = rb[i] < 0 ? 0 : ((long)(rb[i] * p.H + riy[i]) * p.W + rix[i]);
+    }
+    bool uni_b = true;
+    long aff_off = 0;
+    if (PK == PK_AFFINE && p.pre_bstride != 0) {
+        const int m_lo = mt * BM, m_hi = min(mt * BM + BM - 1, p.M - 1);
+        uni_b = (m_lo / hw) == (m_hi / hw);
+        aff_off = (long)(m_lo / hw) * p.pre_bstride;
+    }
+    const int2* ktab = p.ktab + (long)phase * (p.K_pad >> 2);
+    // weight panels: hi then lo, each [cout_pad][k_pad] halves
+    const _Float16* wh = p.wpack_h + ((long)phase * 2 * p.Cout_pad + (long)nt * BN) * p.K_pad;
+    const _Float16* wl = wh + (long)p.Cout_pad * p.K_pad;
+    int brow[BPL], bpiece[BPL];
+#pragma unroll
+    for (int j = 0; j < BPL; ++j) {
+        const int q = t + 256 * j;
+        brow[j] = q >> 2;
+        bpiece[j] = q & 3;
+    }
+
+    f32x4 areg[AP];
+    u32x4 bhreg[BPL], blreg[BPL];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    unsigned okmask = 0;
+    int st_cidx = 0;
+    int2 e_next = make_int2(0, (int)0x80000000);
+
+    auto issue = [&](int s, bool prefetch) {
+        const int2 e = e_next;
+        if (prefetch) e_next = ktab[(s + 1) * 8 + kc];
+        const int dy = (int)(short)(e.x & 0xffff);
+        const int dx = e.x >> 16;
+        const bool inval = e.y < 0;
+        const int src = (e.y >> 30) & 1;
+        const int coff = e.y & 0x3fffffff;
+        const float* base = src ? p.src1 : p.src0;
+        const int Cs = src ? p.Cs1 : p.Cs0;
+        st_cidx = coff + (src ? p.C0 : 0);
+        if (PK == PK_AFFINE && uni_b) {
+            sc = *(const f32x4*)(p.pre_scale + aff_off + st_cidx);
+            sh = *(const f32x4*)(p.pre_shift + aff_off + st_cidx);
+        }
+        const long tapoff = (long)(dy * p.W + dx) * Cs + coff;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            int iy = riy[i] + dy, ix = rix[i] + dx;
+            bool ok = rb[i] >= 0 && !inval;
+            long off;
+            if (GEN) {
+                if (p.pad_mode == FUSG_PAD_REFLECT) {
+                    iy = iy < 0 ? -iy : (iy >= p.Hv ? 2 * p.Hv - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= p.Wv ? 2 * p.Wv - 2 - ix : ix);
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+                }
+                iy >>= p.ups; ix >>= p.ups;
+                off = ((long)(rb[i] * p.H + iy) * p.W + ix) * Cs + coff;
+            } else {
+                ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                off = rowoff[i] * Cs + tapoff;
+            }
+            off = ok ? off : 0;
+            areg[i] = *(const f32x4*)(base + off);
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
+                const long o = (long)brow[j] * p.K_pad + s * BK + bpiece[j] * 8;
+                bhreg[j] = *(const u32x4*)(wh + o);
+                blreg[j] = *(const u32x4*)(wl + o);
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        _Float16* ah = Ah + buf * BM * LDH + r0 * LDH + kc * 4;
+        _Float16* al = Al + buf * BM * LDH + r0 * LDH + kc * 4;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            f32x4 v = areg[i];
+            if (PK == PK_ELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
+            } else if (PK == PK_AFFINE) {
+                if (!uni_b) {
+                    const long o = (long)max(rb[i], 0) * p.pre_bstride + st_cidx;
+                    sc = *(const f32x4*)(p.pre_scale + o);
+                    sh = *(const f32x4*)(p.pre_shift + o);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc[c], sh[c]);
+            }
+            if (PK != PK_ELU && p.pre_relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+            const bool ok = (okmask >> i) & 1u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
+            h4 hi, lo;
+            split4(v, hi, lo);
+            *(h4*)(ah + 32 * i * LDH) = hi;
+            *(h4*)(al + 32 * i * LDH) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
+                *(u32x4*)(Bh + buf * BN * LDH + brow[j] * LDH + bpiece[j] * 8) = bhreg[j];
+                *(u32x4*)(Bl + buf * BN * LDH + brow[j] * LDH + bpiece[j] * 8) = blreg[j];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    const int s_begin = ks * p.steps_per_split;
+    const int s_end = min(p.nk, s_begin + p.steps_per_split);
+
+    if (s_begin < s_end) {
+        e_next = ktab[s_begin * 8 + kc];
+        issue(s_begin, s_begin + 1 < s_end);
+        commit(0);
+        __syncthreads();
+        const int a_off = (wm * TM * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+        const int b_off = (wn * TN * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            const bool more = s + 1 < s_end;
+            if (more) issue(s + 1, s + 2 < s_end);
+            const _Float16* ahb = Ah + buf * BM * LDH + a_off;
+            const _Float16* alb = Al + buf * BM * LDH + a_off;
+            const _Float16* bhb = Bh + buf * BN * LDH + b_off;
+            const _Float16* blb = Bl + buf * BN * LDH + b_off;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *(const h8*)(ahb + i * 32 * LDH + c * 16);
+                    al[i] = *(const h8*)(alb + i * 32 * LDH + c * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    bh[i] = *(const h8*)(bhb + i * 32 * LDH + c * 16);
+                    bl[i] = *(const h8*)(blb + i * 32 * LDH + c * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accx[i][j][r] * (1.f / H3_SCALE);
+
+    const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    const int mrow0 = mt * BM + wm * TM * 32 + 4 * (lane >> 5);
+    if (p.ksplit > 1) {
+        float* ws = p.ws + ((long)(phase * p.ksplit + ks) * p.M) * p.Cout_pad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ws[(long)m * p.Cout_pad + ncol0 + j * 32] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    PixOff co[TN];
+    float bias[TN];
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        nok[j] = n < p.Cout;
+        bias[j] = p.bias[n];
+        chan_offsets(p, n, co[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            PixOff po;
+            if (pix_offsets(p, phase, m, po)) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+            }
+        }
+}
+
+template <int TM, int TN, int WM, int WN>
+hipError_t launch_h3(const ConvK& k, dim3 grid, hipStream_t s, int pk, bool gen) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * LDH * sizeof(_Float16);
+    const void* fn = nullptr;
+#define FUSG_PICK(PKV, GENV) fn = (const void*)conv_igemm_h3<TM, TN, WM, WN, PKV, GENV>
+    if (pk == PK_NONE) { if (gen) FUSG_PICK(PK_NONE, true); else FUSG_PICK(PK_NONE, false); }
+    else if (pk == PK_ELU) { if (gen) FUSG_PICK(PK_ELU, true); else FUSG_PICK(PK_ELU, false); }
+    else { if (gen) FUSG_PICK(PK_AFFINE, true); else FUSG_PICK(PK_AFFINE, false); }
+#undef FUSG_PICK
+    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+    if (!attr_done[pk][gen ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[pk][gen ? 1 : 0] = true;
+    }
+    ConvK kk = k;
+    void* args[] = {(void*)&kk};
+    return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
+}
+
+}  // namespace fusg

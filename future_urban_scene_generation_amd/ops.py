@@ -18,6 +18,20 @@ from .pack import ConvPlan
 
 _DT = {torch.float32: L.F32, torch.uint8: L.U8, torch.int32: L.I32}
 
+# Arithmetic of the conv contraction (include/fusg.h fusg_precision): "f32" = exact fp32 MFMA,
+# "f16x3" = split-fp16 (fp32-class accuracy, 3 passes at the fp16 matrix rate).  Process-wide default,
+# overridable per call; FUSG_PRECISION in the environment sets the initial value.
+import os as _os
+_PREC = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
+PRECISION = _os.environ.get("FUSG_PRECISION", "f16x3")
+
+
+def set_precision(name: str) -> None:
+    global PRECISION
+    if name not in _PREC:
+        raise ValueError(f"precision must be one of {list(_PREC)}")
+    PRECISION = name
+
 
 def _require_gpu(t: torch.Tensor, what: str = "input") -> None:
     if not t.is_cuda:
@@ -113,7 +127,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
          out_c_off: int = 0, res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
          pre_op: int = L.PRE_NONE, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_bstride: int = 0,
          act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
-         ksplit: int = 0) -> torch.Tensor:
+         ksplit: int = 0, precision: Optional[str] = None) -> torch.Tensor:
     """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
     unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result)."""
     plan.to(x0.device)
@@ -163,6 +177,8 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         d.out_sy = d.out_sx = 1
     d.dst_c_off = int(out_c_off)
     d.tile, d.ksplit = int(tile), int(ksplit)
+    d.precision = _PREC[precision or PRECISION]
+    d.wpack_h = dev["wpack_h"].data_ptr()
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None

@@ -56,6 +56,7 @@ class ConvPlan:
                         "ktab": self.ktab.to(device).contiguous()}
             if self.rowsplit is not None:
                 self.dev["rs_bias"] = self.rowsplit["bias"].to(device).contiguous()
+            self.dev["wpack_h"] = split_f16x3(self.wpack).to(device).contiguous()
         return self
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
@@ -66,6 +67,18 @@ class ConvPlan:
         pw = self.pad if self.pad_w < 0 else self.pad_w
         return ((hv + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1,
                 (wv + 2 * pw - self.dil * (self.kw - 1) - 1) // self.stride + 1)
+
+
+H3_SCALE = 2048.0
+
+
+def split_f16x3(wpack: torch.Tensor) -> torch.Tensor:
+    """[nphase, cout_pad, k_pad] f32 -> [nphase, 2, cout_pad, k_pad] f16 = (hi, (w - hi) * 2^11):
+    the weight half of the split-precision contraction (csrc/conv_kernel_h3.h)."""
+    w = wpack.clamp(-65504.0, 65504.0)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * H3_SCALE).to(torch.float16)
+    return torch.stack([hi, lo], dim=1)
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):

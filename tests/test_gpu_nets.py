@@ -14,6 +14,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["f32", "f16x3"], autouse=True)
+def precision(request):
+    """Every GPU parity test runs on both contraction paths: exact fp32 MFMA and split-fp16."""
+    from future_urban_scene_generation_amd import ops as _ops
+    old = _ops.PRECISION
+    _ops.set_precision(request.param)
+    yield request.param
+    _ops.set_precision(old)
+
 import oracle                                                              # noqa: E402
 from conftest import load_golden, load_schema, synth_sd                    # noqa: E402
 from future_urban_scene_generation_amd import ops                          # noqa: E402
