@@ -1,11 +1,12 @@
 // Split-precision variant of the fused implicit-GEMM convolution (gfx950): fp32 operands are split
-// on the fly into fp16 (hi, lo*2^11) pairs and multiplied on the fp16 matrix cores
-// (v_mfma_f32_32x32x16_f16, fp32 accumulate) as  a*w ~= ah*wh + (ah*wl + al*wh) / 2^11.
-// fp16 x fp16 products are exact in fp32 (11+11 significant bits), the scaled lo parts keep 11 more
-// bits of each operand without touching fp16 denormals, and the cross terms accumulate in a second
-// fp32 accumulator that is folded in once in the epilogue - so the result carries ~2^-22 relative
-// error per product (fp32 MFMA: 2^-24) at 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less
-// matrix-pipe time.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
+// on the fly into fp16 (hi, lo) pairs (hi = top 11 significant bits, lo = the fp32 residual rounded
+// to fp16) and multiplied on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate) as
+//     a*w ~= ah*wh + ah*wl + al*wh        (al*wl ~ 2^-22 |a w| is dropped)
+// fp16 x fp16 products are exact in fp32 (11+11 significant bits) and all three terms go into the
+// same fp32 accumulator.  gfx950's fp16 MFMA keeps fp16 subnormals (verified on hardware: the
+// parity suite, including the ill-conditioned ICN fixture, passes bit-for-bit-class with unscaled
+// residuals), so lo needs no scaling: |lo| < 2^-11 |a| simply degrades gracefully to an absolute
+// 2^-25 floor.  Cost: 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less matrix-pipe time.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
 // LDS: four fp16 tiles per buffer ([row][40 halves], 80-byte pitch: conflict-free ds_read_b128).
 #pragma once
 #include "conv_kernel.h"
@@ -17,17 +18,34 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDH = 40;                 // LDS row pitch in halves
-constexpr float H3_SCALE = 2048.f;      // 2^11
 
-__device__ __forceinline__ void split4(const f32x4 v, h4& hi, h4& lo) {
+
+typedef __fp16 h2 __attribute__((ext_vector_type(2)));     // type returned by cvt_pkrtz
+
+// Split 4 fp32 values into fp16 (hi, lo*2^11).  `lo_bound` is -65504 (plain clamp) or 0 (the clamp
+// doubles as the fused ReLU).  hi keeps the top 10 mantissa bits (bit mask: exactly representable
+// in fp16 for normal-range values), the residual is exact in fp32, and both halves are packed with
+// v_cvt_pkrtz_f16_f32.  ~4.5 VALU ops per element.
+__device__ __forceinline__ void split4(const f32x4 v, float lo_bound, h4& hi, h4& lo) {
+    float hf[4], lf[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float a = fminf(fmaxf(v[c], -65504.f), 65504.f);
-        const _Float16 h = (_Float16)a;
-        hi[c] = h;
-        lo[c] = (_Float16)((a - (float)h) * H3_SCALE);
+        const float a = __builtin_amdgcn_fmed3f(v[c], lo_bound, 65504.f);
+        hf[c] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+        lf[c] = a - hf[c];
     }
+    const h2 h01 = __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]), h23 = __builtin_amdgcn_cvt_pkrtz(hf[2], hf[3]);
+    const h2 l01 = __builtin_amdgcn_cvt_pkrtz(lf[0], lf[1]), l23 = __builtin_amdgcn_cvt_pkrtz(lf[2], lf[3]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hp = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    const u32x2 lp = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    hi = __builtin_bit_cast(h4, hp);
+    lo = __builtin_bit_cast(h4, lp);
 }
+
+// 16 zero bytes: out-of-image lanes of the pre-op kinds with f(0) = 0 read this instead of being
+// masked after the load.
+__device__ const f32x4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
 
 template <int TM, int TN, int WM, int WN, int PK, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
@@ -94,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         bpiece[j] = q & 3;
     }
 
+    const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
     f32x4 areg[AP];
     u32x4 bhreg[BPL], blreg[BPL];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -136,9 +155,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                 ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 off = rowoff[i] * Cs + tapoff;
             }
-            off = ok ? off : 0;
-            areg[i] = *(const f32x4*)(base + off);
-            okmask |= (ok ? 1u : 0u) << i;
+            const float* ptr = base + off;
+            if (PK == PK_AFFINE) { ptr = ok ? ptr : base; okmask |= (ok ? 1u : 0u) << i; }
+            else ptr = ok ? ptr : (const float*)&g_zero16;      // relu(0) = elu(0) = 0: no masking needed
+            areg[i] = *(const f32x4*)ptr;
         }
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
@@ -167,15 +187,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaf(v[c], sc[c], sh[c]);
             }
-            if (PK != PK_ELU && p.pre_relu) {
+            if (PK == PK_AFFINE) {
+                const bool ok = (okmask >> i) & 1u;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
             }
-            const bool ok = (okmask >> i) & 1u;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
             h4 hi, lo;
-            split4(v, hi, lo);
+            split4(v, lo_bound, hi, lo);
             *(h4*)(ah + 32 * i * LDH) = hi;
             *(h4*)(al + 32 * i * LDH) = lo;
         }
@@ -188,13 +206,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         }
     };
 
-    f32x16 acc[TM][TN], accx[TM][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int s_begin = ks * p.steps_per_split;
     const int s_end = min(p.nk, s_begin + p.steps_per_split);
@@ -232,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
             if (more) commit(buf ^ 1);
@@ -242,13 +260,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
     }
 
     // ---------------------------------------------------------------- epilogue
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += accx[i][j][r] * (1.f / H3_SCALE);
-
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
     const int mrow0 = mt * BM + wm * TM * 32 + 4 * (lane >> 5);
     if (p.ksplit > 1) {

@@ -69,15 +69,12 @@ class ConvPlan:
                 (wv + 2 * pw - self.dil * (self.kw - 1) - 1) // self.stride + 1)
 
 
-H3_SCALE = 2048.0
-
-
 def split_f16x3(wpack: torch.Tensor) -> torch.Tensor:
-    """[nphase, cout_pad, k_pad] f32 -> [nphase, 2, cout_pad, k_pad] f16 = (hi, (w - hi) * 2^11):
+    """[nphase, cout_pad, k_pad] f32 -> [nphase, 2, cout_pad, k_pad] f16 = (hi, w - hi):
     the weight half of the split-precision contraction (csrc/conv_kernel_h3.h)."""
     w = wpack.clamp(-65504.0, 65504.0)
     hi = w.to(torch.float16)
-    lo = ((w - hi.to(torch.float32)) * H3_SCALE).to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
     return torch.stack([hi, lo], dim=1)
 
 

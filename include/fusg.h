@@ -75,7 +75,7 @@ typedef enum fusg_store_mode {
 
 /* Arithmetic of the conv contraction.
  * F32:   v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (157 TFLOP/s dense peak).
- * F16X3: operands split into fp16 (hi, lo*2^11) pairs, a*w ~= ah*wh + (ah*wl + al*wh)/2^11 on
+ * F16X3: operands split into fp16 (hi, lo) pairs, a*w ~= ah*wh + ah*wl + al*wh on
  *        v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-22 relative error per product
  *        (fp32-class; |x| is clamped to 65504), 3 MFMA passes at the fp16 rate. */
 typedef enum fusg_precision { FUSG_PREC_F32 = 0, FUSG_PREC_F16X3 = 1 } fusg_precision;
@@ -131,7 +131,7 @@ typedef struct fusg_conv_desc {
     int32_t tile;                /* fusg_tile                                                  */
     int32_t ksplit;              /* <=1: no split-K                                            */
     int32_t precision;           /* fusg_precision                                             */
-    const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo*2^11) */
+    const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo)       */
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
