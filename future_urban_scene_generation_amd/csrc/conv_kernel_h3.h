@@ -7,7 +7,9 @@
 // parity suite, including the ill-conditioned ICN fixture, passes bit-for-bit-class with unscaled
 // residuals), so lo needs no scaling: |lo| < 2^-11 |a| simply degrades gracefully to an absolute
 // 2^-25 floor.  Cost: 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less matrix-pipe time.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
-// LDS: four fp16 tiles per buffer ([row][40 halves], 80-byte pitch: conflict-free ds_read_b128).
+// LDS: four fp16 tiles per buffer, [row][32 halves] = 64-byte rows whose four 16-byte chunks are
+// XOR-swizzled with (row >> 2) & 3: conflict-free ds_read_b128 operand fetches without padding, so a
+// 128x128 workgroup needs exactly 64 KiB and two workgroups share a CU's 160 KiB.
 #pragma once
 #include "conv_kernel.h"
 
@@ -17,7 +19,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDH = 40;                 // LDS row pitch in halves
+constexpr int LDH = 32;                 // LDS row pitch in halves (64 B, XOR-swizzled 16-byte chunks)
 
 
 typedef __fp16 h2 __attribute__((ext_vector_type(2)));     // type returned by cvt_pkrtz
@@ -46,6 +48,20 @@ __device__ __forceinline__ void split4(const f32x4 v, float lo_bound, h4& hi, h4
 // 16 zero bytes: out-of-image lanes of the pre-op kinds with f(0) = 0 read this instead of being
 // masked after the load.
 __device__ const f32x4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
+
+// 1 MFMA : FUSG_VALU_PER_MFMA VALU instruction groups for the LLVM scheduler (cdna_hip_programming.md T19)
+#ifndef FUSG_VALU_PER_MFMA
+#define FUSG_VALU_PER_MFMA 8
+#endif
+#if defined(FUSG_FORCE_INTERLEAVE)
+#define FUSG_INTERLEAVE()                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3 * 2 * TM * TN; ++q_) {             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x002, FUSG_VALU_PER_MFMA, 0);      \
+    }
+#else
+#define FUSG_INTERLEAVE()      /* measured on MI355X: the forced 1:8 interleave is ~5% slower than hipcc's own order */
+#endif
 
 template <int TM, int TN, int WM, int WN, int PK, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
@@ -113,14 +129,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
     }
 
     const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
-    f32x4 areg[AP];
-    u32x4 bhreg[BPL], blreg[BPL];
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    unsigned okmask = 0;
-    int st_cidx = 0;
+    struct Stage {
+        f32x4 a[AP];
+        u32x4 bh[BPL], bl[BPL];
+        f32x4 sc, sh;
+        unsigned okmask;
+        int cidx;
+    };
+    Stage st0, st1;                      // two register stages: loads run two K-steps ahead of the MFMAs
     int2 e_next = make_int2(0, (int)0x80000000);
 
-    auto issue = [&](int s, bool prefetch) {
+    auto issue = [&](Stage& S, int s, bool prefetch) {
+        f32x4(&areg)[AP] = S.a;
+        u32x4(&bhreg)[BPL] = S.bh;
+        u32x4(&blreg)[BPL] = S.bl;
+        f32x4& sc = S.sc;
+        f32x4& sh = S.sh;
+        unsigned& okmask = S.okmask;
+        int& st_cidx = S.cidx;
         const int2 e = e_next;
         if (prefetch) e_next = ktab[(s + 1) * 8 + kc];
         const int dy = (int)(short)(e.x & 0xffff);
@@ -169,9 +195,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             }
         }
     };
-    auto commit = [&](int buf) {
-        _Float16* ah = Ah + buf * BM * LDH + r0 * LDH + kc * 4;
-        _Float16* al = Al + buf * BM * LDH + r0 * LDH + kc * 4;
+    auto commit = [&](Stage& S, int buf) {
+        f32x4(&areg)[AP] = S.a;
+        u32x4(&bhreg)[BPL] = S.bh;
+        u32x4(&blreg)[BPL] = S.bl;
+        f32x4& sc = S.sc;
+        f32x4& sh = S.sh;
+        const unsigned okmask = S.okmask;
+        const int st_cidx = S.cidx;
+        // row r0 + 32 i has the same (row >> 2) & 3 for every i, so one swizzled offset serves all passes
+        const int a_sw = ((((kc >> 1) ^ (r0 >> 2)) & 3) << 3) + ((kc & 1) << 2);
+        _Float16* ah = Ah + buf * BM * LDH + r0 * LDH + a_sw;
+        _Float16* al = Al + buf * BM * LDH + r0 * LDH + a_sw;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             f32x4 v = areg[i];
@@ -200,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
             if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
-                *(u32x4*)(Bh + buf * BN * LDH + brow[j] * LDH + bpiece[j] * 8) = bhreg[j];
-                *(u32x4*)(Bl + buf * BN * LDH + brow[j] * LDH + bpiece[j] * 8) = blreg[j];
+                const int sw = ((bpiece[j] ^ (brow[j] >> 2)) & 3) << 3;
+                *(u32x4*)(Bh + buf * BN * LDH + brow[j] * LDH + sw) = bhreg[j];
+                *(u32x4*)(Bl + buf * BN * LDH + brow[j] * LDH + sw) = blreg[j];
             }
         }
     };
@@ -217,46 +253,77 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
     const int s_begin = ks * p.steps_per_split;
     const int s_end = min(p.nk, s_begin + p.steps_per_split);
 
-    if (s_begin < s_end) {
-        e_next = ktab[s_begin * 8 + kc];
-        issue(s_begin, s_begin + 1 < s_end);
-        commit(0);
-        __syncthreads();
-        const int a_off = (wm * TM * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
-        const int b_off = (wn * TN * 32 + (lane & 31)) * LDH + (lane >> 5) * 8;
-        for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            const bool more = s + 1 < s_end;
-            if (more) issue(s + 1, s + 2 < s_end);
-            const _Float16* ahb = Ah + buf * BM * LDH + a_off;
-            const _Float16* alb = Al + buf * BM * LDH + a_off;
-            const _Float16* bhb = Bh + buf * BN * LDH + b_off;
-            const _Float16* blb = Bl + buf * BN * LDH + b_off;
+    auto compute = [&](int buf) {
+        const int a_off = (wm * TM * 32 + (lane & 31)) * LDH;
+        const int b_off = (wn * TN * 32 + (lane & 31)) * LDH;
+        const int rsw = (lane >> 2) & 3;             // (row >> 2) & 3 of this lane's rows
+        const int hh = lane >> 5;                    // which 8 k of a 16-k chunk this lane feeds
+        const _Float16* ahb = Ah + buf * BM * LDH + a_off;
+        const _Float16* alb = Al + buf * BM * LDH + a_off;
+        const _Float16* bhb = Bh + buf * BN * LDH + b_off;
+        const _Float16* blb = Bl + buf * BN * LDH + b_off;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                h8 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int c = 0; c < 2; ++c) {
+            h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[i] = *(const h8*)(ahb + i * 32 * LDH + c * 16);
-                    al[i] = *(const h8*)(alb + i * 32 * LDH + c * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    bh[i] = *(const h8*)(bhb + i * 32 * LDH + c * 16);
-                    bl[i] = *(const h8*)(blb + i * 32 * LDH + c * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const h8*)(ahb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+                al[i] = *(const h8*)(alb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
             }
-            if (more) commit(buf ^ 1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                bh[i] = *(const h8*)(bhb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+                bl[i] = *(const h8*)(blb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // Software pipeline, distance 2: while step s is on the matrix cores, the loads of step s+2 are
+    // in flight (stage registers) and step s+1 is being converted into the other LDS buffer.
+    if (s_begin < s_end) {
+        const int n = s_end - s_begin;
+        e_next = ktab[s_begin * 8 + kc];
+        issue(st0, s_begin, n > 1);
+        if (n > 1) issue(st1, s_begin + 1, n > 2);
+        commit(st0, 0);
+        __syncthreads();
+        int s = s_begin;
+        // steady state: no conditionals inside, so that each half is one scheduling region in which the
+        // staging VALU work (address generation, pre-op, fp16 split) is interleaved with the MFMAs
+        // (in-order issue: a burst of back-to-back MFMAs would otherwise serialise the two pipes).
+        for (; s + 4 < s_end; s += 2) {
+            issue(st0, s + 2, true);
+            compute(0);
+            commit(st1, 1);
+            FUSG_INTERLEAVE();
+            __syncthreads();
+            issue(st1, s + 3, true);
+            compute(1);
+            commit(st0, 0);
+            FUSG_INTERLEAVE();
             __syncthreads();
         }
+        for (; s + 1 < s_end; s += 2) {
+            // even half: compute buf 0 (step s); st1 holds step s+1; refill st0 with step s+2
+            if (s + 2 < s_end) issue(st0, s + 2, s + 3 < s_end);
+            compute(0);
+            commit(st1, 1);
+            __syncthreads();
+            // odd half: compute buf 1 (step s+1); st0 holds step s+2; refill st1 with step s+3
+            if (s + 3 < s_end) issue(st1, s + 3, s + 4 < s_end);
+            compute(1);
+            if (s + 2 < s_end) commit(st0, 0);
+            __syncthreads();
+        }
+        if (s < s_end) compute(0);             // odd count: the last step sits in buffer 0
     }
 
     // ---------------------------------------------------------------- epilogue
