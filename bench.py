@@ -31,6 +31,7 @@ if REPO not in sys.path:
 # algorithmic conv FLOPs per crop at 256x256 (2*MAC, measured on the reference)
 GFLOP_PER_CROP = {"hg": 17.95, "icn": 130.12, "vunet_first": 76.27, "edge": 96.13, "inpaint": 97.37}
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak (no sparsity)
 
 
 def main():
@@ -43,7 +44,9 @@ def main():
     ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="crops in the CPU baseline sample")
-    ap.add_argument("--no-prof", action="store_true", help="disable the per-launch HIP events (roofline leg)")
+    ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default=None,
+                    help="conv contraction: f16x3 = split-fp16 MFMA, fp32-class accuracy (default); f32 = exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch
@@ -65,6 +68,9 @@ def main():
 
     from future_urban_scene_generation_amd import ops
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, synth_batch
+    if args.precision:
+        ops.set_precision(args.precision)
+    prec = ops.PRECISION
 
     torch.set_grad_enabled(False)
     pipe = VehiclePipeline(dev, inpaint=args.inpaint)
@@ -87,17 +93,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    prof = not args.no_prof
     barrier()
-    if prof:
-        ops.prof_reset()
-        ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # Roofline leg: the SAME K steps again with one HIP-event pair around every conv launch, recorded on
+    # the launch stream.  Kept out of the timed region above because ~460 event records per step cost
+    # ~10 % of wall time; kernel durations themselves are unaffected (rocprofv3 agrees, profiles/).
+    prof = not args.no_prof
     if prof:
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(args.steps):
+            step()
+        barrier()
         ops.prof_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -121,9 +132,16 @@ def main():
                 traffic = json.load(open(tpath)).get("conv_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "fusg::conv_igemm_f32 (all tile instantiations)",
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        if prec == "f32":
+            kern, peak, note = "fusg::conv_igemm_f32 (all tile instantiations)", PEAK_F32_MFMA_TFLOPS, \
+                "fp32 MFMA: 1 matrix FLOP per algorithmic FLOP"
+        else:
+            kern, peak, note = "fusg::conv_igemm_h3 (all tile instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
+                ("split-fp16: every algorithmic fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh); peak = dense "
+                 "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
+        roofline = {"bound": "mfma", "kernel": kern,
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "note": note,
                     "launches_per_step": conv_launches // max(1, args.steps),
                     "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
                     "conv_ms_per_step": round(conv_ms / args.steps, 3),
@@ -158,11 +176,13 @@ def main():
         line = {"metric": "synthesised vehicle crops/sec @256x256", "value": round(crops_per_s, 3), "unit": "crops/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None,
+                "dtype": "f32" if prec == "f32" else "f32 operands as 3x f16 split products, f32 accumulate (fp32-class accuracy)",
+                "data": "synthetic",
                 "config": {"workload": ("configs[2]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
                                         if args.inpaint else
                                         "configs[1]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % args.batch,
-                           "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint),
+                           "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint), "precision": prec,
                            "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)

@@ -39,7 +39,9 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("nphase", C.c_int32), ("out_sy", C.c_int32), ("out_sx", C.c_int32),
                 ("out_oy", C.c_int32 * 4), ("out_ox", C.c_int32 * 4),
                 ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
-                ("wpack_h", C.c_void_p)]
+                ("wpack_h", C.c_void_p),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+                ("_pad2", C.c_int32)]
 
 
 # enums (include/fusg.h)

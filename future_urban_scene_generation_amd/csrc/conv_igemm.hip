@@ -1,6 +1,6 @@
 // Host side of the fused implicit-GEMM convolution: descriptor validation, tile / split-K
 // heuristics, launch, and the deterministic split-K slab reduction.  Kernel: conv_kernel.h.
-#include "conv_kernel.h"
+#include "conv_kernel_halo.h"
 
 namespace fusg {
 
@@ -175,6 +175,30 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         default: break;
     }
     const bool gen = d->pad_mode == FUSG_PAD_REFLECT || d->upsample != 0;
+    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->stride == 1 && d->ksplit <= 1 &&
+                         d->kh >= 1 && d->kw >= 1 && d->kh * d->kw > 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
+                         (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
+                         d->k_pad % (d->kh * d->kw) == 0 && getenv("FUSG_NO_HALO") == nullptr;
+    if (halo_ok) {
+        HaloK h;
+        memset(&h, 0, sizeof(h));
+        h.c = k;
+        h.kh = d->kh; h.kw = d->kw; h.dil = d->dil; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
+        h.HH = 8 + (d->kh - 1) * d->dil; h.HW = 16 + (d->kw - 1) * d->dil;
+        h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
+        h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
+        const int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+        h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
+        h.c.ksplit = 1;
+        const int HP = h.HH * h.HW;
+        if (HP * 8 <= 2560 && (size_t)(2 * HP * HPITCH + 4 * bn * LDH) * 2 <= 96 * 1024) {
+            dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
+            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
+            if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+            prof_end(0, s);
+            return FUSG_OK;
+        }
+    }
     if (d->precision == FUSG_PREC_F16X3) {
         switch (d->tile) {
             case FUSG_TILE_128x128: e = launch_h3_128x128(k, grid, s, pk, gen); break;

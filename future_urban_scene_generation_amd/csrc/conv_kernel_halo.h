@@ -1,0 +1,301 @@
+// Halo-tiled split-fp16 convolution for stride-1 k x k layers whose sources have a multiple of 32
+// channels (the layers that carry most of the FLOPs: 3x3 / dilated 3x3 / 5x5(+2x upsample) / 7x1).
+//
+// The generic kernel (conv_kernel_h3.h) re-gathers and re-converts the A operand for every tap: for a
+// 3x3 layer every activation is fetched from L2, pre-processed (ELU / affine+ReLU) and split into
+// fp16 (hi, lo) nine times, and on gfx950 that VALU + L2 work - not the matrix pipe - is what bounds
+// it (measured: MFMA pipe 26 % busy).  Here a workgroup owns an 8 x 16 patch of output pixels of ONE
+// image and BN output channels.  For each 32-channel chunk of the input it stages the patch's halo
+// ((8+(kh-1)d) x (16+(kw-1)d) pixels) ONCE: gather -> pre-op -> fp16 split -> LDS.  All kh*kw taps
+// then read their A fragments from that LDS image at a constant per-tap offset; only the (static,
+// pre-split) weight tile of each (chunk, tap) streams through the double-buffered B stage.  Per
+// output tile this cuts the A-side L2 traffic and the staging VALU work by ~kh*kw.
+//
+// Loop nest: source -> 32-channel chunk -> tap;  K index of a (chunk, tap) weight tile in the packed
+// panel = tap * Ctot + channel (same panels as the generic kernel, no re-packing).
+#pragma once
+#include "conv_kernel_h3.h"
+
+namespace fusg {
+
+constexpr int HPITCH = 40;      // halo LDS pitch in halves (80 B): unswizzled, <= 2-way conflicts, 16-B aligned
+
+struct HaloK {
+    ConvK c;
+    int kh, kw, dil, pad_h, pad_w;
+    int HH, HW;                 // halo extent in (virtual) input pixels
+    int tiles_x, tiles_per_img;
+    int c1k;                    // K-channels of src1 (0 if absent)
+};
+
+__device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, int ox, PixOff& o) {
+    long Y, X, cq = 0;
+    if (p.store_mode == FUSG_STORE_D2S) { Y = 2 * oy; X = 2 * ox; }
+    else if (p.store_mode == FUSG_STORE_S2D) { Y = oy >> 1; X = ox >> 1; cq = (long)(((oy & 1) << 1) | (ox & 1)) * p.Cout; }
+    else { Y = (long)oy * p.osy + p.ooy[0]; X = (long)ox * p.osx + p.oox[0]; }
+    o.d = b * p.dsn + Y * p.dsh + X * p.dsw + (cq + p.dst_c_off) * p.dsc;
+    o.r0 = b * p.r0n + Y * p.r0h + X * p.r0w;
+    o.r1 = b * p.r1n + Y * p.r1h + X * p.r1w;
+}
+
+template <int TM, int TN, int WM, int WN, int PK, int NI>
+__global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
+    const ConvK& p = hk.c;
+    constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
+    constexpr int BN = 32 * TN * WN;
+    static_assert(BM == 128 && WM * WN == 4, "8x16 pixel patch, 4 waves");
+    constexpr int BCH = BN * 4;
+    constexpr int BPL = (BCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    const int HP = hk.HH * hk.HW;
+    _Float16* Ah = smem_h;                         // [HP][HPITCH]
+    _Float16* Al = Ah + HP * HPITCH;
+    _Float16* Bh = Al + HP * HPITCH;               // [2][BN][LDH]   (HP * HPITCH * 2 B is a multiple of 16)
+    _Float16* Bl = Bh + 2 * BN * LDH;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kc = t & 7;
+
+    int tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = tile % p.NT;
+    const int mt = tile / p.NT;
+    const int b = mt / hk.tiles_per_img;
+    const int t2 = mt - b * hk.tiles_per_img;
+    const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+
+    // ---- halo items of this thread: pixel index inside the source image + validity (same for every chunk)
+    int hpix[NI];                                   // iy * W + ix of the (reflected / clamped) source pixel
+    unsigned hvalid = 0;                            // bit j: item j is inside the image (zero padding)
+    unsigned hexist = 0;                            // bit j: item j is a real halo item (j-th pass may overrun HP)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int item = t + 256 * j;
+        const int pix = item >> 3;
+        hpix[j] = 0;
+        if (pix < HP) {
+            hexist |= 1u << j;
+            const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
+            int vy = oy0 - hk.pad_h + hy, vx = ox0 - hk.pad_w + hx;
+            bool ok = true;
+            if (p.pad_mode == FUSG_PAD_REFLECT) {
+                vy = vy < 0 ? -vy : (vy >= p.Hv ? 2 * p.Hv - 2 - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= p.Wv ? 2 * p.Wv - 2 - vx : vx);
+            } else {
+                ok = (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv;
+            }
+            if (ok) { hvalid |= 1u << j; hpix[j] = (vy >> p.ups) * p.W + (vx >> p.ups); }
+        }
+    }
+    const long img_pix0 = (long)b * p.H * p.W;
+
+    const _Float16* wh = p.wpack_h + (long)nt * BN * p.K_pad;
+    const _Float16* wl = wh + (long)p.Cout_pad * p.K_pad;
+    int brow[BPL], bpiece[BPL];
+#pragma unroll
+    for (int j = 0; j < BPL; ++j) {
+        const int q = t + 256 * j;
+        brow[j] = q >> 2;
+        bpiece[j] = q & 3;
+    }
+
+    const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
+    const int nch0 = p.C0 >> 5, nch = nch0 + (hk.c1k >> 5);
+    const int ntaps = hk.kh * hk.kw;
+    const int ctot = p.C0 + hk.c1k;
+    const int total = nch * ntaps;
+
+    f32x4 hreg[NI];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    u32x4 bhreg[BPL], blreg[BPL];
+
+    auto halo_issue = [&](int cg) {
+        const bool s1 = cg >= nch0;
+        const float* base = s1 ? p.src1 : p.src0;
+        const int Cs = s1 ? p.Cs1 : p.Cs0;
+        const int coff = ((s1 ? cg - nch0 : cg) << 5) + kc * 4;
+        if (PK == PK_AFFINE) {
+            const long o = (long)b * p.pre_bstride + (s1 ? p.C0 : 0) + coff;
+            sc = *(const f32x4*)(p.pre_scale + o);
+            sh = *(const f32x4*)(p.pre_shift + o);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float* ptr = base + (img_pix0 + hpix[j]) * Cs + coff;
+            if (PK != PK_AFFINE) ptr = ((hvalid >> j) & 1u) ? ptr : (const float*)&g_zero16;
+            hreg[j] = *(const f32x4*)ptr;
+        }
+    };
+    auto halo_commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            f32x4 v = hreg[j];
+            if (PK == PK_ELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
+            } else if (PK == PK_AFFINE) {
+                const bool ok = (hvalid >> j) & 1u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
+            }
+            h4 hi, lo;
+            split4(v, lo_bound, hi, lo);
+            if ((hexist >> j) & 1u) {
+                const int pix = (t + 256 * j) >> 3;
+                *(h4*)(Ah + pix * HPITCH + kc * 4) = hi;
+                *(h4*)(Al + pix * HPITCH + kc * 4) = lo;
+            }
+        }
+    };
+    auto b_issue = [&](int step) {
+        const int cg = step / ntaps, tap = step - cg * ntaps;
+        const long kbase = (long)tap * ctot + (cg << 5);          // src1 chunks follow src0's inside a tap: cg<<5 already spans both
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
+                const long o = (long)brow[j] * p.K_pad + kbase + bpiece[j] * 8;
+                bhreg[j] = *(const u32x4*)(wh + o);
+                blreg[j] = *(const u32x4*)(wl + o);
+            }
+        }
+    };
+    auto b_commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
+                const int sw = ((bpiece[j] ^ (brow[j] >> 2)) & 3) << 3;
+                *(u32x4*)(Bh + buf * BN * LDH + brow[j] * LDH + sw) = bhreg[j];
+                *(u32x4*)(Bl + buf * BN * LDH + brow[j] * LDH + sw) = blreg[j];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane -> halo pixel of its A rows (tap (0,0)); row = wm*TM*32 + i*32 + (lane&31) -> (py, px) = (row>>4, row&15)
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * TM * 32 + i * 32 + (lane & 31);
+        abase[i] = ((row >> 4) * hk.HW + (row & 15)) * HPITCH + (lane >> 5) * 8;
+    }
+    const int b_off = (wn * TN * 32 + (lane & 31)) * LDH;
+    const int rsw = (lane >> 2) & 3;
+    const int hh = lane >> 5;
+
+    auto compute = [&](int tap, int buf) {
+        const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
+        const int toff = (ky * hk.dil * hk.HW + kx * hk.dil) * HPITCH;
+        const _Float16* bhb = Bh + buf * BN * LDH + b_off;
+        const _Float16* blb = Bl + buf * BN * LDH + b_off;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const h8*)(Ah + abase[i] + toff + c * 16);
+                al[i] = *(const h8*)(Al + abase[i] + toff + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                bh[i] = *(const h8*)(bhb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+                bl[i] = *(const h8*)(blb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- prologue: halo of chunk 0 and the first weight tile
+    halo_issue(0);
+    b_issue(0);
+    halo_commit();
+    b_commit(0);
+    __syncthreads();
+    int step = 0;
+    for (int cg = 0; cg < nch; ++cg) {
+        const bool more_chunks = cg + 1 < nch;
+        if (more_chunks) halo_issue(cg + 1);           // in flight during all taps of this chunk
+        for (int tap = 0; tap < ntaps; ++tap, ++step) {
+            const bool more = step + 1 < total;
+            if (more) b_issue(step + 1);
+            compute(tap, step & 1);
+            if (more) b_commit((step + 1) & 1);
+            if (tap == ntaps - 1 && more_chunks) {
+                __syncthreads();                       // every wave is done with this chunk's halo
+                halo_commit();
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    PixOff co[TN];
+    float bias[TN];
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        nok[j] = n < p.Cout;
+        bias[j] = p.bias[n];
+        chan_offsets(p, n, co[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            PixOff po;
+            pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+        }
+}
+
+template <int TM, int TN, int WM, int WN>
+hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
+    constexpr int BN = 32 * TN * WN;
+    const int HP = k.HH * k.HW;
+    const size_t lds = (size_t)(2 * HP * HPITCH + 2 * 2 * BN * LDH) * sizeof(_Float16);
+    const int ni = (HP * 8 + 255) / 256;
+    const void* fn = nullptr;
+#define FUSG_PICK_NI(PKV)                                                                         \
+    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6>;                            \
+    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8>;                       \
+    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10>;
+    if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU) } else { FUSG_PICK_NI(PK_AFFINE) }
+#undef FUSG_PICK_NI
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    HaloK kk = k;
+    void* args[] = {(void*)&kk};
+    return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
+}
+
+hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int);
+hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int);
+hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int);
+
+}  // namespace fusg

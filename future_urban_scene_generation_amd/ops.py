@@ -179,6 +179,9 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     d.tile, d.ksplit = int(tile), int(ksplit)
     d.precision = _PREC[precision or PRECISION]
     d.wpack_h = dev["wpack_h"].data_ptr()
+    if plan.nphase == 1:                      # dense kh x kw tap grid: lets the library pick the halo-tiled kernel
+        d.kh, d.kw, d.dil = plan.kh, plan.kw, plan.dil
+        d.pad_h, d.pad_w = plan.pad, (plan.pad if plan.pad_w < 0 else plan.pad_w)
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None
