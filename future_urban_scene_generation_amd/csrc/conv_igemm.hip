@@ -160,6 +160,16 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     for (int i = 0; i < 4; ++i) { k.ooy[i] = d->out_oy[i]; k.oox[i] = d->out_ox[i]; }
     k.dst_c_off = d->dst_c_off; k.Cd = d->store_mode == FUSG_STORE_D2S ? d->cout / 4 : d->cout;
     k.ksplit = d->ksplit; k.steps_per_split = (k.nk + d->ksplit - 1) / d->ksplit;
+    {   // 16-byte epilogue accesses need channel-contiguous, 16-byte aligned destinations and residuals
+        auto vec_ok = [](const fusg_tensor& t) {
+            return t.sc == 1 && (((uintptr_t)t.data) & 15) == 0 && t.sw % 4 == 0 && t.sh % 4 == 0 && t.sn % 4 == 0;
+        };
+        bool v = d->cout % 4 == 0 && d->dst_c_off % 4 == 0 && vec_ok(o) && getenv("FUSG_NO_VEC_EPI") == nullptr;
+        if (d->store_mode == FUSG_STORE_D2S) v = v && (d->cout / 4) % 4 == 0;
+        if (d->res0.data) v = v && vec_ok(d->res0);
+        if (d->res1.data) v = v && vec_ok(d->res1);
+        k.vec_epi = v ? 1 : 0;
+    }
 
     dim3 grid(k.MT * k.NT, nphase, d->ksplit);
     const double flops = 2.0 * (double)Ml * d->cout * d->k_pad * nphase;   // padded-K flops; bench uses algorithmic ones
@@ -187,7 +197,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.HH = 8 + (d->kh - 1) * d->dil; h.HW = 16 + (d->kw - 1) * d->dil;
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
-        const int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+        int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+        if (const char* ev = getenv("FUSG_HALO_BN")) { const int v = atoi(ev); if ((v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v; }
         h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
         const int HP = h.HH * h.HW;

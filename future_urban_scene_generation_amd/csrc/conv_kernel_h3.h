@@ -343,6 +343,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             }
         return;
     }
+    if (p.vec_epi) {
+        __syncthreads();                                   // all waves are done with the staging buffers
+        float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
+        const int mwave = mt * BM + wm * TM * 32;
+        epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32,
+                             [&](int row, PixOff& po) { return pix_offsets(p, phase, mwave + row, po); });
+        return;
+    }
     PixOff co[TN];
     float bias[TN];
     bool nok[TN];

@@ -251,6 +251,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
 
     // ---------------------------------------------------------------- epilogue
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    if (p.vec_epi) {
+        __syncthreads();
+        float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
+        const int rwave = wm * TM * 32;
+        epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, [&](int row, PixOff& po) {
+            const int rr = rwave + row;
+            pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
+            return true;
+        });
+        return;
+    }
     PixOff co[TN];
     float bias[TN];
     bool nok[TN];
@@ -278,7 +289,8 @@ template <int TM, int TN, int WM, int WN>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     constexpr int BN = 32 * TN * WN;
     const int HP = k.HH * k.HW;
-    const size_t lds = (size_t)(2 * HP * HPITCH + 2 * 2 * BN * LDH) * sizeof(_Float16);
+    size_t lds = (size_t)(2 * HP * HPITCH + 2 * 2 * BN * LDH) * sizeof(_Float16);
+    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
     const int ni = (HP * 8 + 255) / 256;
     const void* fn = nullptr;
 #define FUSG_PICK_NI(PKV)                                                                         \
