@@ -120,3 +120,25 @@ def test_rowsplit_head_matches_conv():
                 out[:, co, :, xo] += t[:, co * 7 + kx, :, xx]
     ref = F.conv2d(F.pad(x, (3,) * 4, mode="reflect"), w, b)
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_f16x3_split_is_fp32_class():
+    """The split-fp16 contraction a*w ~= ah*wh + ah*wl + al*wh (csrc/conv_kernel_h3.h): emulate it with
+    exact fp64 products of the fp16 parts and compare with plain fp16 and with fp32 rounding."""
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(256, 512, generator=g)
+    w = torch.randn(512, 64, generator=g) * 0.05
+    exact = a.double() @ w.double()
+    wsplit = pack.split_f16x3(w.t().contiguous()[None])[0]              # [2, 64, 512] (hi, lo)
+    wh, wl = wsplit[0].t().double(), wsplit[1].t().double()
+    ah = (a.view(torch.int32) & -8192).view(torch.float32)             # kernel: top 11 significant bits
+    al = (a - ah).half()
+    ah, al = ah.double(), al.double()
+    x3 = ah @ wh + ah @ wl + al @ wh
+    scale = (a.abs().double() @ w.abs().double())
+    e3 = ((x3 - exact).abs() / scale).max().item()
+    e1 = ((a.half().double() @ w.half().double() - exact).abs() / scale).max().item()
+    e32 = (((a @ w).double() - exact).abs() / scale).max().item()
+    assert e3 < 2e-6 and e3 < e1 / 200, (e3, e1, e32)                  # ~2^-21 vs fp16's ~2^-11
+    big = a.abs() >= 2.0 ** -14                                        # fp16 normal range
+    assert (ah.float().half().float() == ah.float())[big].all()        # hi is exactly representable in fp16 there
