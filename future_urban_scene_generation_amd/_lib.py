@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
                 ("wpack_h", C.c_void_p),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("_pad2", C.c_int32)]
+                ("_pad2", C.c_int32), ("wfrag", C.c_void_p)]
 
 
 # enums (include/fusg.h)

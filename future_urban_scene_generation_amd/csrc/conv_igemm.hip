@@ -188,7 +188,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->stride == 1 && d->ksplit <= 1 &&
                          d->kh >= 1 && d->kw >= 1 && d->kh * d->kw > 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
-                         d->k_pad % (d->kh * d->kw) == 0 && getenv("FUSG_NO_HALO") == nullptr;
+                         d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
+                         getenv("FUSG_NO_HALO") == nullptr;
     if (halo_ok) {
         HaloK h;
         memset(&h, 0, sizeof(h));
@@ -197,12 +198,14 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.HH = 8 + (d->kh - 1) * d->dil; h.HW = 16 + (d->kw - 1) * d->dil;
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
+        h.wfrag = (const _Float16*)d->wfrag;
+        h.nt32 = d->cout_pad / 32;
         int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
         if (const char* ev = getenv("FUSG_HALO_BN")) { const int v = atoi(ev); if ((v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v; }
         h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
         const int HP = h.HH * h.HW;
-        if (HP * 8 <= 2560 && (size_t)(2 * HP * HPITCH + 4 * bn * LDH) * 2 <= 96 * 1024) {
+        if (HP * 8 <= 2560 && (size_t)(2 * HP * HPITCH) * 2 <= 96 * 1024) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }

@@ -11,6 +11,11 @@
 // pre-split) weight tile of each (chunk, tap) streams through the double-buffered B stage.  Per
 // output tile this cuts the A-side L2 traffic and the staging VALU work by ~kh*kw.
 //
+// Weights never touch LDS: pack.py stores them a second time in MFMA-fragment order, so the B operand of
+// every (tap, chunk, 32-column tile, 16-k half) is ONE contiguous 1 KiB wave load (16 B per lane) that
+// goes straight into registers, one step ahead of its use.  Waves therefore only meet at chunk
+// boundaries (two barriers per kh*kw taps) instead of once per tap.
+//
 // Loop nest: source -> 32-channel chunk -> tap;  K index of a (chunk, tap) weight tile in the packed
 // panel = tap * Ctot + channel (same panels as the generic kernel, no re-packing).
 #pragma once
@@ -26,6 +31,8 @@ struct HaloK {
     int HH, HW;                 // halo extent in (virtual) input pixels
     int tiles_x, tiles_per_img;
     int c1k;                    // K-channels of src1 (0 if absent)
+    const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
+    int nt32;                   // cout_pad / 32
 };
 
 __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, int ox, PixOff& o) {
@@ -44,14 +51,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
     static_assert(BM == 128 && WM * WN == 4, "8x16 pixel patch, 4 waves");
-    constexpr int BCH = BN * 4;
-    constexpr int BPL = (BCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int HP = hk.HH * hk.HW;
     _Float16* Ah = smem_h;                         // [HP][HPITCH]
     _Float16* Al = Ah + HP * HPITCH;
-    _Float16* Bh = Al + HP * HPITCH;               // [2][BN][LDH]   (HP * HPITCH * 2 B is a multiple of 16)
-    _Float16* Bl = Bh + 2 * BN * LDH;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -97,16 +100,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
     }
     const long img_pix0 = (long)b * p.H * p.W;
 
-    const _Float16* wh = p.wpack_h + (long)nt * BN * p.K_pad;
-    const _Float16* wl = wh + (long)p.Cout_pad * p.K_pad;
-    int brow[BPL], bpiece[BPL];
-#pragma unroll
-    for (int j = 0; j < BPL; ++j) {
-        const int q = t + 256 * j;
-        brow[j] = q >> 2;
-        bpiece[j] = q & 3;
-    }
-
+    // this wave's weight fragments: tiles (nt*BN/32 + wn*TN + j), j < TN
+    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 4 * 64 + lane) * 8;
+    const long wstep = (long)hk.nt32 * 4 * 64 * 8;            // halves per (tap, chunk) slab
     const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
     const int nch0 = p.C0 >> 5, nch = nch0 + (hk.c1k >> 5);
     const int ntaps = hk.kh * hk.kw;
@@ -115,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
 
     f32x4 hreg[NI];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    u32x4 bhreg[BPL], blreg[BPL];
 
     auto halo_issue = [&](int cg) {
         const bool s1 = cg >= nch0;
@@ -155,27 +150,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
             }
         }
     };
-    auto b_issue = [&](int step) {
+    struct BFrag { h8 f[TN][2][2]; };                 // [column tile][k half][hi, lo]
+    BFrag bfA, bfB;
+    auto b_load = [&](BFrag& F, int step) {
         const int cg = step / ntaps, tap = step - cg * ntaps;
-        const long kbase = (long)tap * ctot + (cg << 5);          // src1 chunks follow src0's inside a tap: cg<<5 already spans both
+        const _Float16* base = wfr + (long)(tap * nch + cg) * wstep;
 #pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
-                const long o = (long)brow[j] * p.K_pad + kbase + bpiece[j] * 8;
-                bhreg[j] = *(const u32x4*)(wh + o);
-                blreg[j] = *(const u32x4*)(wl + o);
-            }
-        }
-    };
-    auto b_commit = [&](int buf) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            if (BCH >= 256 * (j + 1) || t + 256 * j < BCH) {
-                const int sw = ((bpiece[j] ^ (brow[j] >> 2)) & 3) << 3;
-                *(u32x4*)(Bh + buf * BN * LDH + brow[j] * LDH + sw) = bhreg[j];
-                *(u32x4*)(Bl + buf * BN * LDH + brow[j] * LDH + sw) = blreg[j];
-            }
-        }
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    F.f[j][c][hl] = *(const h8*)(base + ((j * 2 + c) * 2 + hl) * 512);
     };
 
     f32x16 acc[TM][TN];
@@ -193,61 +179,53 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
         const int row = wm * TM * 32 + i * 32 + (lane & 31);
         abase[i] = ((row >> 4) * hk.HW + (row & 15)) * HPITCH + (lane >> 5) * 8;
     }
-    const int b_off = (wn * TN * 32 + (lane & 31)) * LDH;
-    const int rsw = (lane >> 2) & 3;
-    const int hh = lane >> 5;
-
-    auto compute = [&](int tap, int buf) {
+    auto compute = [&](int tap, const BFrag& F) {
         const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
         const int toff = (ky * hk.dil * hk.HW + kx * hk.dil) * HPITCH;
-        const _Float16* bhb = Bh + buf * BN * LDH + b_off;
-        const _Float16* blb = Bl + buf * BN * LDH + b_off;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            h8 ah[TM], al[TM], bh[TN], bl[TN];
+            h8 ah[TM], al[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *(const h8*)(Ah + abase[i] + toff + c * 16);
                 al[i] = *(const h8*)(Al + abase[i] + toff + c * 16);
             }
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                bh[i] = *(const h8*)(bhb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
-                bl[i] = *(const h8*)(blb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
-            }
-#pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], F.f[j][c][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], F.f[j][c][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], F.f[j][c][0], acc[i][j], 0, 0, 0);
                 }
         }
     };
 
-    // ---- prologue: halo of chunk 0 and the first weight tile
+    // ---- prologue: halo of chunk 0 and the first weight fragments
     halo_issue(0);
-    b_issue(0);
+    b_load(bfA, 0);
     halo_commit();
-    b_commit(0);
     __syncthreads();
-    int step = 0;
-    for (int cg = 0; cg < nch; ++cg) {
-        const bool more_chunks = cg + 1 < nch;
-        if (more_chunks) halo_issue(cg + 1);           // in flight during all taps of this chunk
-        for (int tap = 0; tap < ntaps; ++tap, ++step) {
-            const bool more = step + 1 < total;
-            if (more) b_issue(step + 1);
-            compute(tap, step & 1);
-            if (more) b_commit((step + 1) & 1);
-            if (tap == ntaps - 1 && more_chunks) {
-                __syncthreads();                       // every wave is done with this chunk's halo
+    int cg = 0, tap = 0;
+    auto one_step = [&](const BFrag& use, BFrag& fill, int step) {
+        if (tap == 0 && cg + 1 < nch) halo_issue(cg + 1);          // in flight during all taps of this chunk
+        if (step + 1 < total) b_load(fill, step + 1);
+        compute(tap, use);
+        if (++tap == ntaps) {
+            tap = 0;
+            if (++cg < nch) {
+                __syncthreads();                                   // every wave is done with the old halo
                 halo_commit();
+                __syncthreads();
             }
-            __syncthreads();
         }
+    };
+    int step = 0;
+    for (; step + 1 < total; step += 2) {
+        one_step(bfA, bfB, step);
+        one_step(bfB, bfA, step + 1);
     }
+    if (step < total) one_step(bfA, bfB, step);
 
     // ---------------------------------------------------------------- epilogue
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
@@ -289,7 +267,7 @@ template <int TM, int TN, int WM, int WN>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     constexpr int BN = 32 * TN * WN;
     const int HP = k.HH * k.HW;
-    size_t lds = (size_t)(2 * HP * HPITCH + 2 * 2 * BN * LDH) * sizeof(_Float16);
+    size_t lds = (size_t)(2 * HP * HPITCH) * sizeof(_Float16);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
     const int ni = (HP * 8 + 255) / 256;
     const void* fn = nullptr;

@@ -182,6 +182,8 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     if plan.nphase == 1:                      # dense kh x kw tap grid: lets the library pick the halo-tiled kernel
         d.kh, d.kw, d.dil = plan.kh, plan.kw, plan.dil
         d.pad_h, d.pad_w = plan.pad, (plan.pad if plan.pad_w < 0 else plan.pad_w)
+        if dev.get("wfrag") is not None:
+            d.wfrag = dev["wfrag"].data_ptr()
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None

@@ -56,7 +56,10 @@ class ConvPlan:
                         "ktab": self.ktab.to(device).contiguous()}
             if self.rowsplit is not None:
                 self.dev["rs_bias"] = self.rowsplit["bias"].to(device).contiguous()
-            self.dev["wpack_h"] = split_f16x3(self.wpack).to(device).contiguous()
+            wsplit = split_f16x3(self.wpack)
+            self.dev["wpack_h"] = wsplit.to(device).contiguous()
+            frag = frag_f16x3(wsplit, self) if self.nphase == 1 else None
+            self.dev["wfrag"] = None if frag is None else frag.to(device).contiguous()
         return self
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
@@ -76,6 +79,22 @@ def split_f16x3(wpack: torch.Tensor) -> torch.Tensor:
     hi = w.to(torch.float16)
     lo = (w - hi.to(torch.float32)).to(torch.float16)
     return torch.stack([hi, lo], dim=1)
+
+
+def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:
+    """MFMA-fragment order of the split weights for the halo kernel (csrc/conv_kernel_halo.h):
+    [tap][chunk32][cout_pad/32][k half (16)][hi|lo][lane 64][8 halves], lane = (k>>3 & 1)*32 + column,
+    i.e. exactly what lane l of a wave feeds v_mfma_f32_32x32x16_f16 as B[k = 8*(l>>5) + j][col = l&31].
+    Returns None when the layer cannot use that kernel (channels not a multiple of 32 per source)."""
+    taps = plan.kh * plan.kw
+    ctot = plan.c0k + plan.c1k
+    if plan.nphase != 1 or taps < 2 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
+        return None
+    w = wsplit[0]                                               # [2 (hi, lo), cout_pad, k_pad]
+    nt32, nch = plan.cout_pad // 32, ctot // 32
+    w = w.view(2, nt32, 32, taps, nch, 2, 2, 8)                 # hl, nt, r, tap, chunk, c16, h, j
+    w = w.permute(3, 4, 1, 5, 0, 6, 2, 7)                       # tap, chunk, nt, c16, hl, h, r, j
+    return w.reshape(taps, nch, nt32, 2, 2, 64, 8).contiguous()
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):

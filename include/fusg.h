@@ -138,6 +138,10 @@ typedef struct fusg_conv_desc {
      * dy = ky*dil - pad_h, dx = kx*dil - pad_w, which is what pack.py emits. */
     int32_t kh, kw, dil, pad_h, pad_w;
     int32_t _pad2;
+    /* Halo kernel only: the (hi, lo) fp16 weights again, in MFMA-fragment order
+     * [tap][chunk32][cout_pad/32][k-half][hi|lo][64 lanes][8 halves] (pack.py: frag_f16x3), so that a
+     * B operand is one contiguous 1 KiB wave load.  NULL disables the halo kernel. */
+    const void*    wfrag;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
