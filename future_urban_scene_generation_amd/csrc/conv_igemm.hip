@@ -47,6 +47,11 @@ static int64_t plan_impl(fusg_conv_desc* d) {
         if (tiles < 256 && bn == 64) { bm = 64; }
         d->tile = bm == 128 ? (bn == 128 ? FUSG_TILE_128x128 : bn == 64 ? FUSG_TILE_128x64 : FUSG_TILE_128x32)
                             : FUSG_TILE_64x64;
+        // Split-fp16 generic kernel: staging-bound rather than matrix-bound, so the 64-row tiles (32
+        // accumulator VGPRs per 64x128, 48 KiB LDS -> 3 workgroups/CU) beat the 128-row ones by 10-20 %
+        // on every large layer measured (tools/bench_layer.py); the 32-wide tile only exists as 128x32.
+        if (d->precision == FUSG_PREC_F16X3 && bm == 128 && bn >= 64)
+            d->tile = bn == 128 ? FUSG_TILE_64x128 : FUSG_TILE_64x64;
     }
     const TileCfg tc = kTiles[d->tile];
     const long tiles = ((M + tc.bm - 1) / tc.bm) * (d->cout_pad / tc.bn) * nphase;

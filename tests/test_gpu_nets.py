@@ -194,3 +194,20 @@ def test_batch_consistency_icn():
     for b in range(3):
         one = model("icn")(x[b:b + 1])
         assert _rel(one, full[b:b + 1].cpu()) < 1e-4      # tile / chunk choices depend on B
+
+
+def test_high_res_512(precision):
+    """BASELINE configs[4] resolution: the same modules at 512x512 (all kernels are resolution-agnostic;
+    Vunet_fix_res.forward asserts 256 like the reference, the four sub-calls do not)."""
+    if precision != "f16x3":
+        pytest.skip("one precision is enough at this size")
+    x = synth_inputs("icn", 1, 512)["x"]
+    out = model("icn")(x.to(DEV))
+    ref = oracle.icn_forward(synth_sd("icn"), x)
+    assert tuple(out.shape) == (1, 3, 512, 512) and _rel(out, ref) < 2e-3
+    assert oracle.ssim(ops.to_image_u8(out).cpu().numpy(), oracle.to_image_u8(ref)) >= 0.999
+    hx = synth_inputs("hg", 1, 512)["x"]
+    hm = model("hg")(hx.to(DEV))["heatmaps"][-1]
+    href = oracle.hourglass_forward(synth_sd("hg"), hx)["heatmaps"][-1]
+    assert tuple(hm.shape) == (1, 12, 128, 128)
+    assert np.array_equal(ops.argmax_hw(hm).cpu().numpy(), oracle.heatmap_argmax(href))
