@@ -190,14 +190,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
                 ah[i] = *(const h8*)(Ah + abase[i] + toff + c * 16);
                 al[i] = *(const h8*)(Al + abase[i] + toff + c * 16);
             }
+            // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one
+            // accumulator stalls the issue: measured SQ_WAIT_INST_ANY 50 % with the accumulator-major order)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], F.f[j][c][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], F.f[j][c][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], F.f[j][c][0], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i], F.f[j][c][term == 1 ? 1 : 0],
+                                                                           acc[i][j], 0, 0, 0);
         }
     };
 
