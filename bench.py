@@ -8,15 +8,18 @@ One *step* = one pass of the hot path over one batch of synthetic crops per rank
 hourglass (+argmax) -> ICN -> VUnet first-frame (enc_up, enc_down, dec_up, dec_down) -> uint8
 quantisation [+ EdgeGenerator + InpaintGenerator with --inpaint], then (N > 1) the gather of the
 rendered uint8 crops to rank 0 over RCCL.  The default workload is BASELINE.json configs[1]:
-batch 32 of 256x256 crops per GPU, fp32 (the reference's dtype) on the fp32 matrix-core path.
+batch 32 of 256x256 crops per GPU.  fp32 tensors (the reference's dtype) everywhere; the conv
+contraction runs either as exact fp32 MFMA (--precision f32) or, by default, as split-fp16 MFMA with
+fp32-class accuracy (f16x3) - both pass the same parity suite.
 Inputs and weights are synthetic (no datasets / checkpoints in this environment) and resident in
 HBM before the timed region; VUnet's sampler noise is drawn on the CPU generator inside the step,
 as the reference does.  Weak scaling: each rank processes its own batch (vehicles are independent).
 
-Extra fields: "roofline" (conv implicit-GEMM kernel: algorithmic FLOPs of SURVEY.md §8d divided by
-the kernel's HIP-event time, measured live over the timed region on the launch stream) and
-"cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's
-cores on a bounded sample of the same workload; N=1, rank 0 only).
+Extra fields: "roofline" (conv kernels: algorithmic FLOPs of SURVEY.md §8d divided by the kernels'
+HIP-event time on the launch stream, measured live in a second pass of the same K steps),
+"cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's cores
+on a bounded sample of the same workload; N=1, rank 0 only), "ssim_vs_cpu_ref" / "kp_idx_exact"
+(quality of the GPU path on that very sample) and "clip_mode" (secondary figure: 8 vehicles x 6 frames).
 """
 import argparse
 import json
@@ -43,7 +46,8 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="crops in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
+    ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
     ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default=None,
                     help="conv contraction: f16x3 = split-fp16 MFMA, fp32-class accuracy (default); f32 = exact fp32 MFMA")
@@ -136,7 +140,7 @@ def main():
             kern, peak, note = "fusg::conv_igemm_f32 (all tile instantiations)", PEAK_F32_MFMA_TFLOPS, \
                 "fp32 MFMA: 1 matrix FLOP per algorithmic FLOP"
         else:
-            kern, peak, note = "fusg::conv_igemm_h3 (all tile instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
+            kern, peak, note = "fusg::conv_halo_h3 + fusg::conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
                 ("split-fp16: every algorithmic fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh); peak = dense "
                  "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
         roofline = {"bound": "mfma", "kernel": kern,
@@ -147,8 +151,24 @@ def main():
                     "conv_ms_per_step": round(conv_ms / args.steps, 3),
                     "alg_gflop_per_launch": round(gflop_crop * args.batch * args.steps / max(1, conv_launches), 3)}
 
-    cpu_baseline = None
     extra = {}
+    if rank == 0 and world == 1 and not args.no_clip and not args.inpaint:
+        # secondary figure: clip mode = 1 HG + 6 ICN + 1 VUnet-full + 5 VUnet-later per vehicle,
+        # 8 vehicles x 6 frames per pass (ICN and the VUnet shape half run at batch 48)
+        from future_urban_scene_generation_amd.pipeline import synth_clip
+        V, F = 8, 6
+        clip = synth_clip(V, F, args.res, dev)
+        pipe.run_clip(clip)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            pipe.run_clip(clip)
+        torch.cuda.synchronize()
+        cdt = (time.perf_counter() - t1) / 3
+        extra["clip_mode"] = {"vehicles": V, "frames": F, "ms_per_pass": round(cdt * 1e3, 3),
+                              "vehicle_clips_per_s": round(V / cdt, 2), "frames_per_s": round(V * F / cdt, 1)}
+        del clip
+    cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         from future_urban_scene_generation_amd.pipeline import load_schema
@@ -173,15 +193,15 @@ def main():
         extra["kp_idx_exact"] = bool(np.array_equal(got["kp_idx"].cpu().numpy(), ref["kp_idx"]))
 
     if rank == 0:
-        line = {"metric": "synthesised vehicle crops/sec @256x256", "value": round(crops_per_s, 3), "unit": "crops/s",
+        line = {"metric": "synthesised vehicle crops/sec @%dx%d" % (args.res, args.res), "value": round(crops_per_s, 3), "unit": "crops/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
                 "dtype": "f32" if prec == "f32" else "f32 operands as 3x f16 split products, f32 accumulate (fp32-class accuracy)",
                 "data": "synthetic",
-                "config": {"workload": ("configs[2]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
+                "config": {"workload": ("configs[2]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
                                         if args.inpaint else
-                                        "configs[1]: batch=%d 256x256 crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % args.batch,
+                                        "configs[1]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % (args.batch, args.res, args.res),
                            "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint), "precision": prec,
                            "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}

@@ -109,6 +109,42 @@ class VehiclePipeline:
         return out
 
 
+    @torch.no_grad()
+    def run_clip(self, clip: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Clip mode = what traj_test does per vehicle over a 6-frame clip: 1x hourglass,
+        F x ICN, 1x VUnet appearance half, F x VUnet shape half with the frame-0 appearance code reused
+        (trajectory_inference.py:75-79, 182, 387-391, 230-233, 424-426) - but batched over vehicles AND
+        frames instead of the reference's two nested serial loops.
+
+        clip: 'hg_x' [V,3,R,R], 'icn_x' [V,F,21,R,R], 'vu_x' [V,6,R,R], 'vu_y' [V,F,3,R,R].
+        Returns 'kp_idx' int32 [V,12], 'icn_u8' / 'vunet_u8' uint8 [V,F,R,R,3]."""
+        from . import ops
+        V, F = clip["icn_x"].shape[:2]
+        R = clip["hg_x"].shape[-1]
+        out = {"kp_idx": ops.argmax_hw(self.hg(clip["hg_x"])["heatmaps"][-1])}
+        icn = self.icn(clip["icn_x"].reshape(V * F, 21, R, R))
+        out["icn_u8"] = ops.to_image_u8(icn).view(V, F, R, R, 3)
+        vu = self.vunet
+        eo, es = vu.forward_enc_up(clip["vu_x"])
+        mu_app, _ = vu.forward_enc_down(eo, es)
+        # every frame of a vehicle conditions on that vehicle's appearance code: frame-major repeat
+        mu_rep = [m.repeat_interleave(F, dim=0) for m in mu_app]
+        do, ds = vu.forward_dec_up(clip["vu_y"].reshape(V * F, 3, R, R))
+        xt, _, _ = vu.forward_dec_down(do, ds, mu_rep)
+        out["vunet_u8"] = ops.to_image_u8(xt).view(V, F, R, R, 3)
+        return out
+
+
+def synth_clip(vehicles: int, frames: int, res: int, device, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic clip-mode inputs (vehicle-major, then frame)."""
+    from .synth import synth_inputs
+    v = synth_inputs("vunet", vehicles, res, seed)
+    return {"hg_x": synth_inputs("hg", vehicles, res, seed)["x"].to(device),
+            "icn_x": synth_inputs("icn", vehicles * frames, res, seed)["x"].view(vehicles, frames, 21, res, res).to(device),
+            "vu_x": v["x"].to(device),
+            "vu_y": synth_inputs("vunet", vehicles * frames, res, seed + 1)["y_tilde"].view(vehicles, frames, 3, res, res).to(device)}
+
+
 def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int = 0) -> Dict[str, torch.Tensor]:
     """Synthetic, device-resident inputs of the shapes/ranges the reference feeds."""
     from .synth import synth_inputs

@@ -211,3 +211,30 @@ def test_high_res_512(precision):
     href = oracle.hourglass_forward(synth_sd("hg"), hx)["heatmaps"][-1]
     assert tuple(hm.shape) == (1, 12, 128, 128)
     assert np.array_equal(ops.argmax_hw(hm).cpu().numpy(), oracle.heatmap_argmax(href))
+
+
+def test_clip_mode_matches_frame_by_frame(precision):
+    """Batched clip mode (vehicles x frames in one pass) == the reference's per-vehicle, per-frame call
+    sequence, given the same noise: frame f of vehicle v uses vehicle v's frame-0 appearance code."""
+    if precision != "f16x3":
+        pytest.skip("one precision is enough")
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_clip
+    V, F, R = 2, 3, 128
+    pipe = VehiclePipeline(DEV)
+    clip = synth_clip(V, F, R, DEV)
+    torch.manual_seed(21)
+    out = pipe.run_clip(clip)
+    assert tuple(out["vunet_u8"].shape) == (V, F, R, R, 3) and tuple(out["icn_u8"].shape) == (V, F, R, R, 3)
+    # oracle, same batched noise stream: enc (V draws), then one dec_down over V*F samples
+    sd = synth_sd("vunet")
+    cpu = {k: v.cpu() for k, v in clip.items()}
+    torch.manual_seed(21)
+    eo, es = oracle.vunet_enc_up(sd, cpu["vu_x"])
+    mu_app, _ = oracle.vunet_enc_down(sd, eo, es)
+    do, ds = oracle.vunet_dec_up(sd, cpu["vu_y"].reshape(V * F, 3, R, R))
+    xt = oracle.vunet_dec_down(sd, do, ds, [m.repeat_interleave(F, dim=0) for m in mu_app])[0]
+    ref = oracle.to_image_u8(xt).reshape(V, F, R, R, 3)
+    got = out["vunet_u8"].cpu().numpy()
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and oracle.ssim(got.reshape(-1, R, R, 3), ref.reshape(-1, R, R, 3)) >= 0.999
+    icn_ref = oracle.to_image_u8(oracle.icn_forward(synth_sd("icn"), cpu["icn_x"].reshape(V * F, 21, R, R))).reshape(V, F, R, R, 3)
+    assert np.abs(out["icn_u8"].cpu().numpy().astype(int) - icn_ref.astype(int)).max() <= 1
