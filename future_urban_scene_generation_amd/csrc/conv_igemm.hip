@@ -191,7 +191,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     }
     const bool gen = d->pad_mode == FUSG_PAD_REFLECT || d->upsample != 0;
     const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->stride == 1 && d->ksplit <= 1 &&
-                         d->kh >= 1 && d->kw >= 1 && d->kh * d->kw > 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
+                         d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
                          getenv("FUSG_NO_HALO") == nullptr;

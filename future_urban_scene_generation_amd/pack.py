@@ -88,7 +88,7 @@ def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]
     Returns None when the layer cannot use that kernel (channels not a multiple of 32 per source)."""
     taps = plan.kh * plan.kw
     ctot = plan.c0k + plan.c1k
-    if plan.nphase != 1 or taps < 2 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
+    if plan.nphase != 1 or taps < 1 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
         return None
     w = wsplit[0]                                               # [2 (hi, lo), cout_pad, k_pad]
     nt32, nch = plan.cout_pad // 32, ctot // 32

@@ -133,7 +133,7 @@ typedef struct fusg_conv_desc {
     int32_t precision;           /* fusg_precision                                             */
     const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo)       */
     /* Optional filter geometry (0 = unknown).  When given and the layer qualifies (F16X3, stride 1,
-     * nphase 1, source channels % 32 == 0, qh % 8 == 0, qw % 16 == 0, kh*kw > 1) the halo-tiled kernel
+     * nphase 1, source channels % 32 == 0, qh % 8 == 0, qw % 16 == 0) the halo-tiled kernel
      * is used: taps must then be the dense kh x kw grid in (ky, kx) order with
      * dy = ky*dil - pad_h, dx = kx*dil - pad_w, which is what pack.py emits. */
     int32_t kh, kw, dil, pad_h, pad_w;
