@@ -100,15 +100,17 @@ __global__ __launch_bounds__(256) void copy4d_kernel(T4 s, T4 d, int cfill, long
     for (long c = s.c; c < cfill; ++c) dp[c * d.sc] = 0.f;
 }
 
+// one thread per element, channel fastest (coalesced for NHWC destinations; the Sampler's noise operand is a
+// small NCHW tensor)
 __global__ __launch_bounds__(256) void add4d_kernel(T4 a, T4 bt, T4 d, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const long x = i % d.w; const long r = i / d.w;
+    const long c = i % d.c; long r = i / d.c;
+    const long x = r % d.w; r /= d.w;
     const long y = r % d.h; const long b = r / d.h;
-    const float* ap = (const float*)a.p + b * a.sn + y * a.sh + x * a.sw;
-    const float* bp = (const float*)bt.p + b * bt.sn + y * bt.sh + x * bt.sw;
-    float* dp = (float*)d.p + b * d.sn + y * d.sh + x * d.sw;
-    for (long c = 0; c < d.c; ++c) dp[c * d.sc] = ap[c * a.sc] + bp[c * bt.sc];
+    ((float*)d.p)[b * d.sn + c * d.sc + y * d.sh + x * d.sw] =
+        ((const float*)a.p)[b * a.sn + c * a.sc + y * a.sh + x * a.sw] +
+        ((const float*)bt.p)[b * bt.sn + c * bt.sc + y * bt.sh + x * bt.sw];
 }
 
 // SpaceToDepth(2): dst[b, (2i+j)*C + c, h, w] = x[b, c, 2h+i, 2w+j]; thread per (dst pixel, quadrant, float4)
@@ -304,7 +306,7 @@ extern "C" int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32
 extern "C" int fusg_add4d(const fusg_tensor* a, const fusg_tensor* b, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(a && b && dst && a->data && b->data && dst->data && same_shape(*a, *b) && same_shape(*a, *dst) &&
                a->dtype == FUSG_F32 && b->dtype == FUSG_F32 && dst->dtype == FUSG_F32, "add4d: shape/dtype mismatch");
-    const long total = dst->n * dst->h * dst->w;
+    const long total = dst->n * dst->h * dst->w * dst->c;
     hipLaunchKernelGGL(add4d_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, view(*a), view(*b), view(*dst), total);
     FUSG_LAUNCH_CHECK("add4d");
     return FUSG_OK;

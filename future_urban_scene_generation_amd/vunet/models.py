@@ -185,16 +185,46 @@ class Vunet_fix_res(FusedNet):
     def _upsample(self, name: str, x):
         return ops.conv(self._plans[name + ".depth4x"], x, store=L.STORE_D2S)
 
-    def _sampler(self, name: str, x, mu_out=None, c_off=0, z_out=None):
+    def _draw_noise(self, shapes, device):
+        """All Sampler draws of one entry point, up front: same CPU default generator, same shapes,
+        same order as the reference's `torch.randn(*mu.size())` calls (layers.py:166), but written
+        into one pinned staging buffer and shipped with ONE asynchronous H2D copy instead of ten
+        synchronous ones (each of which would stall the launch queue).  A small ring of staging
+        buffers, guarded by events, keeps a buffer alive until its copy has executed."""
+        total = sum(int(torch.Size(s).numel()) for s in shapes)
+        ring = self.__dict__.setdefault("_noise_ring", [])
+        slot = self.__dict__.get("_noise_slot", 0)
+        self.__dict__["_noise_slot"] = (slot + 1) % 4
+        while len(ring) < 4:
+            ring.append([None, None])
+        buf, ev = ring[slot]
+        if ev is not None:
+            ev.synchronize()                                        # copy issued 4 calls ago: long done
+        if buf is None or buf.numel() < total:
+            buf = torch.empty(max(total, 1 << 16), dtype=torch.float32, pin_memory=True)
+        off, views = 0, []
+        for s in shapes:
+            n = int(torch.Size(s).numel())
+            v = buf[off:off + n].view(*s)
+            torch.randn(*s, out=v)                                  # == torch.randn(*s): same stream, same values
+            views.append((off, n, s))
+            off += n
+        dev_buf = buf[:total].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[slot] = [buf, ev]
+        return [dev_buf[o:o + n].view(*s) for o, n, s in views]
+
+    def _sampler(self, name: str, x, noise, mu_out=None, c_off=0, z_out=None):
         """Sampler (layers.py:163-167).  Returns (mu, z); with mu_out/z_out the results go to the
-        channel slice [c_off, c_off+128) of those buffers."""
+        channel slice [c_off, c_off+128) of those buffers.  `noise` = this sampler's pre-drawn N(0,1)."""
         p = self._plans[name + ".conv"]
         if mu_out is None:
             mu = ops.conv(p, x)
         else:
             ops.conv(p, x, out=mu_out, out_c_off=c_off)
             mu = mu_out[:, c_off:c_off + p.cout]
-        noise = torch.randn(*mu.size()).to(mu.device)             # CPU default generator, like the reference
+        assert tuple(noise.shape) == tuple(mu.shape), (noise.shape, mu.shape)
         z = ops.add4d(mu, noise, None if z_out is None else z_out[:, c_off:c_off + p.cout])
         return mu, z
 
@@ -215,8 +245,8 @@ class Vunet_fix_res(FusedNet):
         x = self._residual(name + ".residual_1", x, skip_b)
         return self._upsample(name + ".up", x)
 
-    def _ar_block(self, name, x, skip_a, enc_down_mu=None):
-        """AutoRegressiveBlock.forward (reference models.py:56-86)."""
+    def _ar_block(self, name, x, skip_a, enc_down_mu, noise):
+        """AutoRegressiveBlock.forward (reference models.py:56-86); `noise` = its four sampler draws."""
         x = self._residual(name + ".residual_init", x, skip_a)
         x_ = ops.space_to_depth2(self._residual(name + ".residual_s2d", x))
         g = None
@@ -227,7 +257,7 @@ class Vunet_fix_res(FusedNet):
         mus = ops.nhwc_empty(b, 512, h, w, x_.device)
         zs = ops.nhwc_empty(b, 512, h, w, x_.device)
         for k in range(4):
-            _, z_k = self._sampler(f"{name}.sampler_{k}", x_, mus, 128 * k, zs)
+            _, z_k = self._sampler(f"{name}.sampler_{k}", x_, noise[k], mus, 128 * k, zs)
             if k < 3:
                 cond = g[k] if g is not None else self._nin(f"{name}.nin_{k}", z_k)
                 x_ = self._residual(f"{name}.residual_{k}", x_, cond)
@@ -266,26 +296,32 @@ class Vunet_fix_res(FusedNet):
         self._ensure(enc_up_outputs[-1])
         P = self._plans
         o1, o2 = ops.as_nhwc(enc_up_outputs[-1]), ops.as_nhwc(enc_up_outputs[-2])
+        b, _, h, w = o1.shape
+        noise = self._draw_noise([(b, 128, h, w), (b, 128, 2 * h, 2 * w)], o1.device)    # 1_b, then 2_b
         x = ops.conv(P["app_bottleneck"], o1)
         x = self._residual("app_decoder_1_a", x, ops.as_nhwc(skips[-1]))
-        mu_0, z_0 = self._sampler("app_decoder_1_b", x)
+        mu_0, z_0 = self._sampler("app_decoder_1_b", x, noise[0])
         x_ = ops.conv(P["app_decoder_1_c"], o2, z_0)
         x = self._residual("app_decoder_1_d", x, x_)
         x = self._upsample("app_decoder_1_e", x)
         x = self._residual("app_decoder_2_a", x, None)
-        mu_1, z_1 = self._sampler("app_decoder_2_b", x)
+        mu_1, z_1 = self._sampler("app_decoder_2_b", x, noise[1])
         return [mu_0, mu_1], [z_0, z_1]
 
     def forward_dec_down(self, dec_up_outputs, skips: List[torch.Tensor], enc_down_mu=()):
         self._ensure(dec_up_outputs[-1])
         P = self._plans
         mu, z = [], []
-        x = ops.conv(P["shape_bottleneck"], ops.as_nhwc(dec_up_outputs[-1]))
+        x0 = ops.as_nhwc(dec_up_outputs[-1])
+        b, _, h, w = x0.shape
+        # reference draw order: block 1 samplers 0..3 at half the bottleneck resolution, then block 2's
+        noise = self._draw_noise([(b, 128, h // 2, w // 2)] * 4 + [(b, 128, h, w)] * 4, x0.device)
+        x = ops.conv(P["shape_bottleneck"], x0)
         for blk in (1, 2):
             skip_a = ops.as_nhwc(skips.pop())
             skip_b = ops.as_nhwc(skips.pop())
             m = None if len(enc_down_mu) == 0 else enc_down_mu[blk - 1]
-            x, mu_k, z_k = self._ar_block(f"shape_decoder_{blk}", x, skip_a, m)
+            x, mu_k, z_k = self._ar_block(f"shape_decoder_{blk}", x, skip_a, m, noise[4 * (blk - 1):4 * blk])
             mu.append(mu_k)
             z.append(z_k)
             x = self._nin(f"shape_decoder_{blk}_n", x, z_k)

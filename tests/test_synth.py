@@ -49,3 +49,21 @@ def test_inputs_do_not_touch_global_rng():
     synth_inputs("vunet", 1, 64)
     synth_inputs("edge", 1, 64)
     assert torch.equal(a, torch.randn(4))
+
+
+def test_randn_out_matches_plain_randn():
+    """The drop-in VUnet draws its sampler noise with torch.randn(*shape, out=staging_view); that must
+    consume the CPU generator exactly like the reference's torch.randn(*shape) (vunet/layers.py:166)."""
+    shapes = [(2, 128, 4, 4), (2, 128, 8, 8), (1, 128, 2, 2), (3, 5, 1, 7)]
+    torch.manual_seed(99)
+    a = [torch.randn(*s) for s in shapes]
+    torch.manual_seed(99)
+    buf = torch.empty(sum(torch.Size(s).numel() for s in shapes) + 13)
+    off, b = 0, []
+    for s in shapes:
+        n = torch.Size(s).numel()
+        v = buf[off:off + n].view(*s)
+        torch.randn(*s, out=v)
+        b.append(v.clone())
+        off += n
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
