@@ -85,16 +85,17 @@ def copy4d(src: torch.Tensor, dst: torch.Tensor, c_fill: int = 0) -> torch.Tenso
     return dst
 
 
-def as_nhwc(t: torch.Tensor) -> torch.Tensor:
+def as_nhwc(t: torch.Tensor, cpad: int = 4) -> torch.Tensor:
     """Return `t` itself if it already is NHWC-physical f32, else a converted copy (channel padding
-    zero-filled).  Used at the module boundary for caller-provided NCHW tensors."""
+    zero-filled).  Used at the module boundary for caller-provided NCHW tensors.  `cpad` > 4 forces a
+    copy whose channel pitch is a multiple of cpad (zero-filled), for layers packed with cin_pad."""
     _require_gpu(t)
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
-    if is_nhwc(t):
+    if cpad == 4 and is_nhwc(t):
         return t
     b, c, h, w = t.shape
-    cp = (c + 3) // 4 * 4
+    cp = (c + cpad - 1) // cpad * cpad
     buf = torch.empty((b, h, w, cp), device=t.device, dtype=torch.float32)
     full = buf.permute(0, 3, 1, 2)
     copy4d(t, full, cp)

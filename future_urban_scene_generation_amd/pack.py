@@ -106,14 +106,14 @@ def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):
     return x, y
 
 
-def _pack_panel(w: torch.Tensor, taps: Sequence[Tuple[int, int, int, int]], c_split: Sequence[int]):
+def _pack_panel(w: torch.Tensor, taps: Sequence[Tuple[int, int, int, int]], c_split: Sequence[int], cin_pad: int = 4):
     """w: [cout, cin, kh, kw] (correlation form).  taps: list of (ky, kx, dy, dx).
     Returns (panel [cout_pad, k_pad], ktab [k_pad/4, 2]) for K order (tap, concat channel)."""
     cout, cin = w.shape[0], w.shape[1]
     assert sum(c_split) == cin, (c_split, cin)
     c0 = c_split[0]
     c1 = c_split[1] if len(c_split) > 1 else 0
-    c0k, c1k = _ru(c0, 4), _ru(c1, 4)
+    c0k, c1k = _ru(c0, cin_pad), _ru(c1, cin_pad)
     ctot = c0k + c1k
     k = len(taps) * ctot
     k_pad = _ru(k, BK)
@@ -135,13 +135,17 @@ def _pack_panel(w: torch.Tensor, taps: Sequence[Tuple[int, int, int, int]], c_sp
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], *, c_split: Optional[Sequence[int]] = None,
-              stride: int = 1, pad: int = 0, dil: int = 1, pad_mode: int = 0, upsample: int = 0) -> ConvPlan:
-    """nn.Conv2d-style filter [cout, cin, kh, kw] -> ConvPlan."""
+              stride: int = 1, pad: int = 0, dil: int = 1, pad_mode: int = 0, upsample: int = 0,
+              cin_pad: int = 4) -> ConvPlan:
+    """nn.Conv2d-style filter [cout, cin, kh, kw] -> ConvPlan.  `cin_pad` = granularity the K-channels of
+    each source are padded to (zero weights): 4 by default, 32 to make a small-Cin k x k layer eligible
+    for the halo kernel (its source buffer must then have a channel pitch >= the padded count, with
+    zeros in the padding: ops.as_nhwc(x, cpad=32))."""
     w = weight.detach().to("cpu", torch.float32)
     cout, cin, kh, kw = w.shape
     c_split = tuple(c_split) if c_split is not None else (cin,)
     taps = [(ky, kx, ky * dil - pad, kx * dil - pad) for ky in range(kh) for kx in range(kw)]
-    panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(w, taps, c_split)
+    panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(w, taps, c_split, cin_pad)
     b = torch.zeros(cout_pad, dtype=torch.float32)
     if bias is not None:
         b[:cout] = bias.detach().to("cpu", torch.float32)
