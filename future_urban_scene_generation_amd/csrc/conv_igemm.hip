@@ -190,7 +190,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         default: break;
     }
     const bool gen = d->pad_mode == FUSG_PAD_REFLECT || d->upsample != 0;
-    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->stride == 1 && d->ksplit <= 1 &&
+    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->upsample + d->stride <= 2 && d->ksplit <= 1 &&
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
@@ -200,7 +200,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         memset(&h, 0, sizeof(h));
         h.c = k;
         h.kh = d->kh; h.kw = d->kw; h.dil = d->dil; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
-        h.HH = 8 + (d->kh - 1) * d->dil; h.HW = 16 + (d->kw - 1) * d->dil;
+        h.stride = d->stride;
+        h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
         h.wfrag = (const _Float16*)d->wfrag;
@@ -210,7 +211,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
         const int HP = h.HH * h.HW;
-        if (HP * 8 <= 2560 && (size_t)(2 * HP * HPITCH) * 2 <= 96 * 1024) {
+        if (HP * 4 <= 2560 && (size_t)(2 * HP * (HP * 8 > 2560 ? 24 : 40)) * 2 <= 96 * 1024) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }

@@ -23,7 +23,8 @@
 
 namespace fusg {
 
-constexpr int HPITCH = 40;      // halo LDS pitch in halves (80 B): unswizzled, <= 2-way conflicts, 16-B aligned
+// halo LDS pitch in halves = CH + 8 (80 B for 32-channel chunks, 48 B for 16): unswizzled, <= 2-way conflicts,
+// 16-byte aligned rows
 
 struct HaloK {
     ConvK c;
@@ -31,6 +32,7 @@ struct HaloK {
     int HH, HW;                 // halo extent in (virtual) input pixels
     int tiles_x, tiles_per_img;
     int c1k;                    // K-channels of src1 (0 if absent)
+    int stride;                 // 1 or 2 (stride-2 layers stage 16-channel chunks: their halo is ~4x larger)
     const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
     int nt32;                   // cout_pad / 32
 };
@@ -45,8 +47,13 @@ __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, in
     o.r1 = b * p.r1n + Y * p.r1h + X * p.r1w;
 }
 
-template <int TM, int TN, int WM, int WN, int PK, int NI>
+template <int TM, int TN, int WM, int WN, int PK, int NI, int CH>
 __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
+    constexpr int HPITCH = CH + 8;                 // halves
+    constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
+    constexpr int LOGC = CH == 32 ? 3 : 2;
+    constexpr int NC16 = CH / 16;                  // 16-k MFMA chunks per staged chunk
+    static_assert(CH == 32 || CH == 16, "chunk size");
     const ConvK& p = hk.c;
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int kc = t & 7;
+    const int kc = t & (CPP - 1);
 
     int tile;
     {
@@ -82,12 +89,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int item = t + 256 * j;
-        const int pix = item >> 3;
+        const int pix = item >> LOGC;
         hpix[j] = 0;
         if (pix < HP) {
             hexist |= 1u << j;
             const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
-            int vy = oy0 - hk.pad_h + hy, vx = ox0 - hk.pad_w + hx;
+            int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
             bool ok = true;
             if (p.pad_mode == FUSG_PAD_REFLECT) {
                 vy = vy < 0 ? -vy : (vy >= p.Hv ? 2 * p.Hv - 2 - vy : vy);
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
     const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 4 * 64 + lane) * 8;
     const long wstep = (long)hk.nt32 * 4 * 64 * 8;            // halves per (tap, chunk) slab
     const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
-    const int nch0 = p.C0 >> 5, nch = nch0 + (hk.c1k >> 5);
+    const int nch0 = p.C0 / CH, nch = nch0 + hk.c1k / CH;
+    const int nch32 = (p.C0 + hk.c1k) >> 5;
     const int ntaps = hk.kh * hk.kw;
     const int ctot = p.C0 + hk.c1k;
     const int total = nch * ntaps;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
         const bool s1 = cg >= nch0;
         const float* base = s1 ? p.src1 : p.src0;
         const int Cs = s1 ? p.Cs1 : p.Cs0;
-        const int coff = ((s1 ? cg - nch0 : cg) << 5) + kc * 4;
+        const int coff = (s1 ? cg - nch0 : cg) * CH + kc * 4;
         if (PK == PK_AFFINE) {
             const long o = (long)b * p.pre_bstride + (s1 ? p.C0 : 0) + coff;
             sc = *(const f32x4*)(p.pre_scale + o);
@@ -144,24 +152,25 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
             h4 hi, lo;
             split4(v, lo_bound, hi, lo);
             if ((hexist >> j) & 1u) {
-                const int pix = (t + 256 * j) >> 3;
+                const int pix = (t + 256 * j) >> LOGC;
                 *(h4*)(Ah + pix * HPITCH + kc * 4) = hi;
                 *(h4*)(Al + pix * HPITCH + kc * 4) = lo;
             }
         }
     };
-    struct BFrag { h8 f[TN][2][2]; };                 // [column tile][k half][hi, lo]
+    struct BFrag { h8 f[TN][NC16][2]; };              // [column tile][16-k chunk][hi, lo]
     BFrag bfA, bfB;
     auto b_load = [&](BFrag& F, int step) {
         const int cg = step / ntaps, tap = step - cg * ntaps;
-        const _Float16* base = wfr + (long)(tap * nch + cg) * wstep;
+        const int k16 = cg * NC16;                                  // first 16-k chunk of this staged chunk
+        const _Float16* base = wfr + (long)(tap * nch32 + (k16 >> 1)) * wstep;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC16; ++c)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl)
-                    F.f[j][c][hl] = *(const h8*)(base + ((j * 2 + c) * 2 + hl) * 512);
+                    F.f[j][c][hl] = *(const h8*)(base + ((j * 2 + (k16 & 1) + c) * 2 + hl) * 512);
     };
 
     f32x16 acc[TM][TN];
@@ -177,13 +186,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wm * TM * 32 + i * 32 + (lane & 31);
-        abase[i] = ((row >> 4) * hk.HW + (row & 15)) * HPITCH + (lane >> 5) * 8;
+        abase[i] = ((row >> 4) * hk.stride * hk.HW + (row & 15) * hk.stride) * HPITCH + (lane >> 5) * 8;
     }
     auto compute = [&](int tap, const BFrag& F) {
         const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
         const int toff = (ky * hk.dil * hk.HW + kx * hk.dil) * HPITCH;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC16; ++c) {
             h8 ah[TM], al[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -269,14 +278,16 @@ template <int TM, int TN, int WM, int WN>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     constexpr int BN = 32 * TN * WN;
     const int HP = k.HH * k.HW;
-    size_t lds = (size_t)(2 * HP * HPITCH) * sizeof(_Float16);
+    const bool ch16 = HP * 8 > 2560;                  // big (stride-2) halos are staged 16 channels at a time
+    size_t lds = (size_t)(2 * HP * (ch16 ? 24 : 40)) * sizeof(_Float16);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
-    const int ni = (HP * 8 + 255) / 256;
+    const int ni = (HP * (ch16 ? 4 : 8) + 255) / 256;
     const void* fn = nullptr;
 #define FUSG_PICK_NI(PKV)                                                                         \
-    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6>;                            \
-    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8>;                       \
-    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10>;
+    if (ch16) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 16>;                          \
+    else if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, 32>;                   \
+    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, 32>;                   \
+    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 32>;
     if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU) } else { FUSG_PICK_NI(PK_AFFINE) }
 #undef FUSG_PICK_NI
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
