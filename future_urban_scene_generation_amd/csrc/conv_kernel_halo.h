@@ -20,6 +20,9 @@
 // panel = tap * Ctot + channel (same panels as the generic kernel, no re-packing).
 #pragma once
 #include "conv_kernel_h3.h"
+#ifndef FUSG_HALO_WAVES
+#define FUSG_HALO_WAVES 2
+#endif
 
 namespace fusg {
 
@@ -48,7 +51,7 @@ __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, in
 }
 
 template <int TM, int TN, int WM, int WN, int PK, int NI, int CH>
-__global__ __launch_bounds__(256, 2) void conv_halo_h3(const HaloK hk) {
+__global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK hk) {
     constexpr int HPITCH = CH + 8;                 // halves
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
     constexpr int LOGC = CH == 32 ? 3 : 2;

@@ -238,3 +238,32 @@ def test_clip_mode_matches_frame_by_frame(precision):
     assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and oracle.ssim(got.reshape(-1, R, R, 3), ref.reshape(-1, R, R, 3)) >= 0.999
     icn_ref = oracle.to_image_u8(oracle.icn_forward(synth_sd("icn"), cpu["icn_x"].reshape(V * F, 21, R, R))).reshape(V, F, R, R, 3)
     assert np.abs(out["icn_u8"].cpu().numpy().astype(int) - icn_ref.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (72, 88)])
+def test_non_square_and_odd_tiles(H, W, precision):
+    """Fully-convolutional behaviour on non-square inputs: 64x96 exercises the halo-tiled kernel with
+    rectangular tile grids, 72x88 (not multiples of 8/16 after down-sampling) the generic gather."""
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.rand(2, 21, H, W, generator=g) * 2 - 1
+    out = model("icn")(x.to(DEV))
+    ref = oracle.icn_forward(synth_sd("icn"), x)
+    assert tuple(out.shape) == (2, 3, H, W) and _rel(out, ref) < 2e-3
+    img = torch.rand(2, 3, H, W, generator=g)
+    gray = img.mean(1, keepdim=True)
+    edge = (torch.rand(2, 1, H, W, generator=g) < 0.05).float()
+    mask = torch.zeros(2, 1, H, W)
+    mask[:, :, H // 4:H // 2, W // 3:2 * W // 3] = 1
+    em = EdgeModel(None)
+    em.generator.load_state_dict(synth_sd("edge"))
+    em = em.to(DEV).eval()
+    e = em(gray.to(DEV), edge.to(DEV), mask.to(DEV))
+    assert _rel(e, oracle.edge_model_forward(synth_sd("edge"), gray, edge, mask)) < 2e-3
+
+
+def test_hourglass_non_square(precision):
+    x = synth_inputs("hg", 1, 256)["x"][:, :, :128, :192].contiguous()
+    hm = model("hg")(x.to(DEV))["heatmaps"][-1]
+    ref = oracle.hourglass_forward(synth_sd("hg"), x)["heatmaps"][-1]
+    assert tuple(hm.shape) == (1, 12, 32, 48) and _rel(hm, ref) < 2e-3
+    assert np.array_equal(ops.argmax_hw(hm).cpu().numpy(), oracle.heatmap_argmax(ref))
