@@ -102,6 +102,26 @@ __global__ __launch_bounds__(256) void copy4d_kernel(T4 s, T4 d, int cfill, long
 
 // one thread per element, channel fastest (coalesced for NHWC destinations; the Sampler's noise operand is a
 // small NCHW tensor)
+// NCHW-contiguous -> NHWC with zero-filled channel padding, through an LDS tile so that both the reads
+// (256 consecutive pixels of one channel plane) and the writes (256 pixels x Cp consecutive floats) are
+// coalesced.  C <= 32.  grid (ceil(HW/256), B).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int Cp, int dCs, long HW) {
+    __shared__ float tile[32][257];
+    const int t = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 256;
+    const long b = blockIdx.y;
+    const int np = (int)min((long)256, HW - p0);
+    for (int c = 0; c < C; ++c)
+        if (t < np) tile[c][t] = src[(b * C + c) * HW + p0 + t];
+    __syncthreads();
+    float* d = dst + (b * HW + p0) * dCs;
+    for (int i = t; i < np * Cp; i += 256) {
+        const int pix = i / Cp, c = i - pix * Cp;
+        d[(long)pix * dCs + c] = c < C ? tile[c][pix] : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void add4d_kernel(T4 a, T4 bt, T4 d, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -296,6 +316,15 @@ extern "C" int fusg_upsample2_add(const fusg_tensor* low, const fusg_tensor* up1
 extern "C" int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32_t dst_c_fill, void* stream) {
     FUSG_CHECK(src && dst && src->data && dst->data && src->dtype == FUSG_F32 && dst->dtype == FUSG_F32, "copy4d: f32 tensors required");
     FUSG_CHECK(same_nhw(*src, *dst) && src->c <= dst->c && dst_c_fill <= dst->c, "copy4d: shape mismatch");
+    const long HW = src->h * src->w;
+    const bool src_nchw = src->sw == 1 && src->sh == src->w && src->sc == HW && src->sn == src->c * HW;
+    if (src_nchw && is_nhwc(*dst) && src->c <= 32 && dst_c_fill <= 32 && dst_c_fill <= dst->sw) {
+        const int cp = dst_c_fill > src->c ? dst_c_fill : (int)src->c;
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)src->n), dim3(256), 0,
+                           (hipStream_t)stream, (const float*)src->data, (float*)dst->data, (int)src->c, cp, (int)dst->sw, HW);
+        FUSG_LAUNCH_CHECK("nchw_to_nhwc");
+        return FUSG_OK;
+    }
     const long total = src->n * src->h * src->w;
     hipLaunchKernelGGL(copy4d_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, view(*src), view(*dst),
                        (int)dst_c_fill, total);
