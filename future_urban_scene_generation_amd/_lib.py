@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
                 ("wpack_h", C.c_void_p),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("_pad2", C.c_int32), ("wfrag", C.c_void_p)]
+                ("_pad2", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p)]
 
 
 # enums (include/fusg.h)
@@ -61,6 +61,9 @@ _SIGS = {
     "fusg_in_finalize": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fusg_ln_finalize": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "fusg_in_finalize_slots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fusg_ln_finalize_slots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "fusg_affine_act": (C.c_int, [_TP, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, _TP, _TP, C.c_void_p]),
     "fusg_maxpool2": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_upsample2_add": (C.c_int, [_TP, _TP, _TP, C.c_void_p]),

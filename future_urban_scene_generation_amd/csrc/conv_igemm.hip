@@ -175,6 +175,16 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         if (d->res1.data) v = v && vec_ok(d->res1);
         k.vec_epi = v ? 1 : 0;
     }
+    if (d->stats_out) {
+        if (!(k.vec_epi && d->act == FUSG_ACT_NONE && !d->res0.data && !d->res1.data && d->store_mode == FUSG_STORE_NORMAL &&
+              nphase == 1 && d->ksplit <= 1 && ((long)d->qh * d->qw) % 32 == 0)) {
+            set_error("conv2d: fused statistics need act NONE, no residual, NORMAL store, nphase 1, ksplit 1, qh*qw%%32==0 "
+                      "and a channel-contiguous aligned dst with cout%%4==0");
+            return FUSG_ERR_UNSUPPORTED;
+        }
+        k.stats = d->stats_out;
+        k.stats_slots = (int)(((long)d->qh * d->qw) / 32);
+    }
 
     dim3 grid(k.MT * k.NT, nphase, d->ksplit);
     const double flops = 2.0 * (double)Ml * d->cout * d->k_pad * nphase;   // padded-K flops; bench uses algorithmic ones

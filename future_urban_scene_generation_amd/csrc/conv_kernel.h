@@ -49,6 +49,8 @@ struct ConvK {
     int pre_relu;            // ReLU after the (optional) affine pre-op
     const _Float16* wpack_h; // f16x3 path: [nphase][2 (hi, lo)][cout_pad][k_pad] halves
     int vec_epi;             // destination / residuals allow 16-byte channel-contiguous epilogue accesses
+    float* stats;            // optional fused norm statistics: [B][stats_slots][Cout][2] = (mean, M2) per 32-pixel slot
+    int stats_slots;         // slots per image = qh*qw/32
 };
 
 enum { PK_NONE = 0, PK_ELU = 1, PK_AFFINE = 2 };   // compile-time pre-op kind
@@ -110,9 +112,9 @@ __device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, cons
 // comes back pixel-major, so each lane handles 4 consecutive channels of one pixel with 16-byte
 // accesses: 4x fewer memory instructions, 256-byte contiguous runs per pixel.
 // `pix(row, po)` maps a row of the wave tile to its destination pixel offsets (false = out of range).
-template <int TM, int TN, typename PixFn>
+template <int TM, int TN, typename PixFn, typename StatFn>
 __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const f32x16 (&acc)[TM][TN], int lane,
-                                             int ncol_base, PixFn pix) {
+                                             int ncol_base, PixFn pix, StatFn stat_base) {
     constexpr int PITCH = TN * 32;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -125,22 +127,59 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int Q = TN * 8;                         // float4 groups per row
+    constexpr int R = 64 / Q;                         // rows covered by one wave pass
+    constexpr int ITER = 32 / R;                      // passes per 32-row MFMA tile
+    const int c4 = lane % Q;
+    const int n = ncol_base + c4 * 4;
+    const bool nvalid = n < p.Cout;
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    PixOff co;
+    co.d = co.r0 = co.r1 = 0;
+    if (nvalid) { bs = *(const f32x4*)(p.bias + n); chan_offsets(p, n, co); }
 #pragma unroll
-    for (int it = 0; it < TM * 32 * Q / 64; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / Q, c4 = idx - row * Q;
-        const int n = ncol_base + c4 * 4;
-        PixOff po;
-        if (n < p.Cout && pix(row, po)) {
+    for (int i = 0; i < TM; ++i) {
+        f32x4 vals[ITER];
+        bool full = true;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = i * 32 + it * R + lane / Q;
+            PixOff po;
+            const bool ok = pix(row, po);
+            full = full && ok;
             f32x4 v = *(const f32x4*)(wlds + row * PITCH + c4 * 4);
-            const f32x4 bs = *(const f32x4*)(p.bias + n);
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bs[c], p.act);
-            PixOff co;
-            chan_offsets(p, n, co);
-            if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
-            if (p.res1) v += *(const f32x4*)(p.res1 + po.r1 + co.r1);
-            *(f32x4*)(p.dst + po.d + co.d) = v;
+            vals[it] = v;
+            if (nvalid && ok) {
+                if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
+                if (p.res1) v += *(const f32x4*)(p.res1 + po.r1 + co.r1);
+                *(f32x4*)(p.dst + po.d + co.d) = v;
+            }
+        }
+        // Fused InstanceNorm / LayerNorm statistics: per (32-pixel slot, channel) mean and centred M2 of the
+        // values just produced (two passes over registers, cross-lane sums by wavefront shuffles), combined
+        // deterministically in fp64 by fusg_*_finalize_slots.  Only whole, in-range 32-row tiles take part.
+        if (p.stats != nullptr) {
+            float* sb = stat_base(i);
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) s1 += vals[it];
+#pragma unroll
+            for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s1[c] += __shfl_xor(s1[c], off, 64);
+            const f32x4 mean = s1 * (1.f / 32.f);
+            f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) { const f32x4 dv = vals[it] - mean; m2 += dv * dv; }
+#pragma unroll
+            for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m2[c] += __shfl_xor(m2[c], off, 64);
+            if (full && nvalid && lane < Q && sb != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { sb[(n + c) * 2] = mean[c]; sb[(n + c) * 2 + 1] = m2[c]; }
+            }
         }
     }
 }
@@ -350,7 +389,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
         float* wlds = (float*)smem + wave * (TM * 32 * TN * 32);
         const int mwave = mt * BM + wm * TM * 32;
         epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32,
-                             [&](int row, PixOff& po) { return pix_offsets(p, phase, mwave + row, po); });
+                             [&](int row, PixOff& po) { return pix_offsets(p, phase, mwave + row, po); },
+                             [&](int i) -> float* {
+                                 const int m0 = mwave + i * 32;            // slot = 32-row group inside its image
+                                 if (m0 >= p.M) return nullptr;
+                                 const int hw_ = p.Ho * p.Wo, b_ = m0 / hw_;
+                                 return p.stats + ((long)b_ * p.stats_slots + (m0 - b_ * hw_) / 32) * p.Cout * 2;
+                             });
         return;
     }
     PixOff co[TN];

@@ -348,7 +348,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
         const int mwave = mt * BM + wm * TM * 32;
         epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32,
-                             [&](int row, PixOff& po) { return pix_offsets(p, phase, mwave + row, po); });
+                             [&](int row, PixOff& po) { return pix_offsets(p, phase, mwave + row, po); },
+                             [&](int i) -> float* {
+                                 const int m0 = mwave + i * 32;
+                                 if (m0 >= p.M) return nullptr;
+                                 const int hw_ = p.Ho * p.Wo, b_ = m0 / hw_;
+                                 return p.stats + ((long)b_ * p.stats_slots + (m0 - b_ * hw_) / 32) * p.Cout * 2;
+                             });
         return;
     }
     PixOff co[TN];

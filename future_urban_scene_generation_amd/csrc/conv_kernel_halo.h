@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             const int rr = rwave + row;
             pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
             return true;
+        }, [&](int i) -> float* {                          // slot = (patch index, 32-row group of the patch)
+            return p.stats + ((long)b * p.stats_slots + t2 * 4 + (rwave >> 5) + i) * p.Cout * 2;
         });
         return;
     }

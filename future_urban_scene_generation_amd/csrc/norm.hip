@@ -123,9 +123,103 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     }
 }
 
+// ---- finalisation from the slot statistics fused into the conv epilogue: slots [B][nslots][C][2] =
+// (mean, centred M2) of 32 pixels each.  Equal counts, so mean = avg(mean_s), M2 = sum M2_s + 32 sum (mean_s-mean)^2.
+// Block = 16 channels x 16 slot lanes (128 B contiguous per slot row); grid (ceil(C/16), B).  One pass in fp64:
+// sum of slot means, of their squares and of the slot M2s, then an LDS tree over the slot lanes.
+__global__ __launch_bounds__(256) void in_finalize_slots_kernel(const float* __restrict__ slots, int nslots, int C,
+                                                                float eps, float* __restrict__ scale,
+                                                                float* __restrict__ shift) {
+    __shared__ double red[3][256];
+    const int t = threadIdx.x;
+    const int cl = t & 15, sl = t >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int b = blockIdx.y;
+    double sm = 0.0, sq = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float2* s = (const float2*)slots + (long)b * nslots * C + c;
+#pragma unroll 4
+        for (int k = sl; k < nslots; k += 16) {
+            const float2 v = s[(long)k * C];
+            sm += (double)v.x;
+            sq += (double)v.x * (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+    red[0][t] = sm; red[1][t] = sq; red[2][t] = s2;
+    __syncthreads();
+    for (int w = 128; w >= 16; w >>= 1) {
+        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+        __syncthreads();
+    }
+    if (t < 16 && c < C) {
+        const double n = (double)nslots;
+        const double mean = red[0][t] / n;
+        double m2 = red[2][t] + 32.0 * (red[1][t] - red[0][t] * mean);
+        if (m2 < 0.0) m2 = 0.0;
+        const double var = m2 / (32.0 * n);                // biased (F.instance_norm)
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale[(long)b * C + c] = (float)rstd;
+        shift[(long)b * C + c] = (float)(-mean * rstd);
+    }
+}
+
+// one block of 1024 threads per sample; same one-pass fp64 moments over all (slot, channel) pairs
+__global__ __launch_bounds__(1024) void ln_finalize_slots_kernel(const float* __restrict__ slots, int nslots, int C, float eps,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[3][1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long total = (long)nslots * C;                  // (slot, channel) pairs, 32 pixels each
+    const float2* s = (const float2*)slots + (long)b * total;
+    double sm = 0.0, sq = 0.0, s2 = 0.0;
+#pragma unroll 4
+    for (long k = t; k < total; k += 1024) {
+        const float2 v = s[k];
+        sm += (double)v.x;
+        sq += (double)v.x * (double)v.x;
+        s2 += (double)v.y;
+    }
+    red[0][t] = sm; red[1][t] = sq; red[2][t] = s2;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+        __syncthreads();
+    }
+    const double mean = red[0][0] / (double)total;
+    double m2 = red[2][0] + 32.0 * (red[1][0] - red[0][0] * mean);
+    if (m2 < 0.0) m2 = 0.0;
+    const double sd = sqrt(m2 / (32.0 * (double)total - 1.0));             // unbiased std
+    const double inv = 1.0 / (sd + (double)eps);
+    for (int c = t; c < C; c += 1024) {
+        const double sc = (double)gamma[c] * inv;
+        scale[(long)b * C + c] = (float)sc;
+        shift[(long)b * C + c] = (float)((double)beta[c] - mean * sc);
+    }
+}
+
 }  // namespace fusg
 
 using namespace fusg;
+
+extern "C" int fusg_in_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+                                      float* scale, float* shift, void* stream) {
+    FUSG_CHECK(slots && scale && shift && batch >= 1 && nslots >= 1 && channels >= 1, "in_finalize_slots: bad arguments");
+    hipLaunchKernelGGL(in_finalize_slots_kernel, dim3((channels + 15) / 16, batch), dim3(256), 0, (hipStream_t)stream, slots,
+                       nslots, channels, eps, scale, shift);
+    FUSG_LAUNCH_CHECK("in_finalize_slots");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_ln_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+                                      const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+    FUSG_CHECK(slots && scale && shift && gamma && beta && batch >= 1 && nslots >= 1 && channels >= 1 &&
+               (long)nslots * channels * 32 > 1, "ln_finalize_slots: bad arguments");
+    hipLaunchKernelGGL(ln_finalize_slots_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, slots, nslots,
+                       channels, eps, gamma, beta, scale, shift);
+    FUSG_LAUNCH_CHECK("ln_finalize_slots");
+    return FUSG_OK;
+}
 
 extern "C" int fusg_chan_stats(const fusg_tensor* x, float* partial, int32_t nchunk, void* stream) {
     FUSG_CHECK(x && is_nhwc(*x) && x->c % 4 == 0, "chan_stats: x must be NHWC-physical with C%%4==0");

@@ -92,23 +92,16 @@ class _Generator(FusedNet):
     def _run(self, x_nhwc: torch.Tensor) -> torch.Tensor:
         P = self._plans
         AR = L.PRE_AFFINE_RELU
-        c = ops.conv(P["stem"], x_nhwc)
-        st = ops.instnorm_stats(c)
-        c = ops.conv(P["down1"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
-        st = ops.instnorm_stats(c)
-        c = ops.conv(P["down2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
-        st = ops.instnorm_stats(c)
+        c, st = ops.conv_in(P["stem"], x_nhwc)
+        c, st = ops.conv_in(P["down1"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
+        c, st = ops.conv_in(P["down2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         y = ops.affine_act(c, st[0], st[1], L.ACT_RELU)
         for pa, pb in P["mid"]:
-            a = ops.conv(pa, y)
-            sa = ops.instnorm_stats(a)
-            b = ops.conv(pb, a, pre_op=AR, pre=sa, pre_bstride=a.shape[1])
-            sb = ops.instnorm_stats(b)
+            a, sa = ops.conv_in(pa, y)
+            b, sb = ops.conv_in(pb, a, pre_op=AR, pre=sa, pre_bstride=a.shape[1])
             y = ops.affine_act(b, sb[0], sb[1], L.ACT_NONE, res=y)
-        c = ops.conv(P["up1"], y)
-        st = ops.instnorm_stats(c)
-        c = ops.conv(P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
-        st = ops.instnorm_stats(c)
+        c, st = ops.conv_in(P["up1"], y)                    # transposed convs: statistics fall back to the streaming pass
+        c, st = ops.conv_in(P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         return ops.conv_rowsplit(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

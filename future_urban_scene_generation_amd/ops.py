@@ -128,7 +128,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
          out_c_off: int = 0, res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
          pre_op: int = L.PRE_NONE, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_bstride: int = 0,
          act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
-         ksplit: int = 0, precision: Optional[str] = None) -> torch.Tensor:
+         ksplit: int = 0, precision: Optional[str] = None, want_stats: bool = False):
     """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
     unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result)."""
     plan.to(x0.device)
@@ -191,8 +191,17 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     if nbytes > 0:
         ws = _workspace(x0.device, nbytes)
         d.workspace = ws.data_ptr()
+    stats = None
+    if want_stats:
+        # fused norm statistics when the launch qualifies (include/fusg.h, stats_out); else the caller falls
+        # back to the separate streaming pass
+        if (d.ksplit <= 1 and plan.nphase == 1 and store == L.STORE_NORMAL and act == L.ACT_NONE and res0 is None
+                and res1 is None and (qh * qw) % 32 == 0 and plan.cout % 4 == 0 and out_c_off % 4 == 0 and is_nhwc(out)
+                and out.stride(3) % 4 == 0):
+            stats = torch.empty((b, qh * qw // 32, plan.cout, 2), device=x0.device, dtype=torch.float32)
+            d.stats_out = stats.data_ptr()
     L.check(lib.fusg_conv2d(C.byref(d), stream_ptr()), "conv2d")
-    return out
+    return (out, stats) if want_stats else out
 
 
 def conv_rowsplit(plan: ConvPlan, x0: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
@@ -243,6 +252,31 @@ def layernorm_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
     L.check(L.lib().fusg_ln_finalize(C.byref(desc(x)), partial.data_ptr(), n, float(eps), gamma.data_ptr(),
                                      beta.data_ptr(), ss[0].data_ptr(), ss[1].data_ptr(), stream_ptr()), "ln_finalize")
     return ss[0], ss[1]
+
+
+def conv_in(plan: ConvPlan, x0: torch.Tensor, eps: float = 1e-5, **kw):
+    """conv followed by InstanceNorm2d statistics: returns (raw conv output, (scale, shift)).  The statistics
+    come out of the conv epilogue when the launch qualifies, else from the streaming pass."""
+    out, stats = conv(plan, x0, want_stats=True, **kw)
+    if stats is None:
+        return out, instnorm_stats(out, eps)
+    b, nslots, c, _ = stats.shape
+    ss = torch.empty((2, b, c), device=out.device, dtype=torch.float32)
+    L.check(L.lib().fusg_in_finalize_slots(stats.data_ptr(), b, nslots, c, float(eps), ss[0].data_ptr(), ss[1].data_ptr(),
+                                           stream_ptr()), "in_finalize_slots")
+    return out, (ss[0], ss[1])
+
+
+def conv_ln(plan: ConvPlan, x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, **kw):
+    """conv followed by the ICN's custom LayerNorm statistics (see layernorm_stats)."""
+    out, stats = conv(plan, x0, want_stats=True, **kw)
+    if stats is None:
+        return out, layernorm_stats(out, gamma, beta, eps)
+    b, nslots, c, _ = stats.shape
+    ss = torch.empty((2, b, c), device=out.device, dtype=torch.float32)
+    L.check(L.lib().fusg_ln_finalize_slots(stats.data_ptr(), b, nslots, c, float(eps), gamma.data_ptr(), beta.data_ptr(),
+                                           ss[0].data_ptr(), ss[1].data_ptr(), stream_ptr()), "ln_finalize_slots")
+    return out, (ss[0], ss[1])
 
 
 def affine_act(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], act: int = L.ACT_NONE,

@@ -138,19 +138,15 @@ class G_Resnet(FusedNet):
     @staticmethod
     def _resblocks(plans, y: torch.Tensor) -> torch.Tensor:
         for pa, pb in plans:
-            a = ops.conv(pa, y)
-            sa = ops.instnorm_stats(a)
-            b = ops.conv(pb, a, pre_op=L.PRE_AFFINE_RELU, pre=sa, pre_bstride=a.shape[1])
-            sb = ops.instnorm_stats(b)
+            a, sa = ops.conv_in(pa, y)                      # InstanceNorm statistics come out of the conv epilogue
+            b, sb = ops.conv_in(pb, a, pre_op=L.PRE_AFFINE_RELU, pre=sa, pre_bstride=a.shape[1])
             y = ops.affine_act(b, sb[0], sb[1], L.ACT_NONE, res=y)
         return y
 
     def _encode(self, P, x: torch.Tensor) -> torch.Tensor:
-        c = ops.conv(P["stem"], ops.as_nhwc(x, cpad=32))
-        st = ops.instnorm_stats(c)
+        c, st = ops.conv_in(P["stem"], ops.as_nhwc(x, cpad=32))
         for p in P["down"]:
-            c = ops.conv(p, c, pre_op=L.PRE_AFFINE_RELU, pre=st, pre_bstride=c.shape[1])
-            st = ops.instnorm_stats(c)
+            c, st = ops.conv_in(p, c, pre_op=L.PRE_AFFINE_RELU, pre=st, pre_bstride=c.shape[1])
         y = ops.affine_act(c, st[0], st[1], L.ACT_RELU)
         return self._resblocks(P["enc_res"], y)
 
@@ -158,8 +154,7 @@ class G_Resnet(FusedNet):
         y = self._resblocks(P["dec_res"], y)
         pre_op, pre, bs = L.PRE_NONE, None, 0
         for p, (gamma, beta, eps) in zip(P["up"], P["ln"]):
-            y = ops.conv(p, y, pre_op=pre_op, pre=pre, pre_bstride=bs)
-            pre = ops.layernorm_stats(y, gamma, beta, eps)
+            y, pre = ops.conv_ln(p, y, gamma, beta, eps, pre_op=pre_op, pre=pre, pre_bstride=bs)
             pre_op, bs = L.PRE_AFFINE_RELU, y.shape[1]
         if P["head"].rowsplit is not None:
             return ops.conv_rowsplit(P["head"], y, pre_op=pre_op, pre=pre, pre_bstride=bs, act=L.ACT_TANH)

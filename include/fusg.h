@@ -142,6 +142,13 @@ typedef struct fusg_conv_desc {
      * [tap][chunk32][cout_pad/32][k-half][hi|lo][64 lanes][8 halves] (pack.py: frag_f16x3), so that a
      * B operand is one contiguous 1 KiB wave load.  NULL disables the halo kernel. */
     const void*    wfrag;
+    /* Optional fused normalisation statistics of the conv OUTPUT (bias included): per image and per
+     * 32-pixel slot (slot order is kernel-defined; finalisation is order-independent) the mean and the
+     * centred sum of squares of every output channel: float [B][qh*qw/32][cout][2].  Requires
+     * act == NONE, no residual, NORMAL store, nphase 1, ksplit <= 1, qh*qw % 32 == 0 and a
+     * channel-contiguous 16-byte aligned dst with cout % 4 == 0 (else FUSG_ERR_UNSUPPORTED).
+     * Feed to fusg_in_finalize_slots / fusg_ln_finalize_slots. */
+    float*         stats_out;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
@@ -162,6 +169,13 @@ int fusg_in_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk,
  * eps added to std: scale[b,c] = gamma[c]/(std+eps), shift[b,c] = beta[c] - mean*scale[b,c]. */
 int fusg_ln_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps,
                      const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+
+/* The same two finalisations from the slot statistics a conv launch produced (fusg_conv_desc.stats_out):
+ * slots [B][nslots][C][2] = (mean, centred M2) over 32 pixels each, combined in fp64 (Chan et al.). */
+int fusg_in_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+                           float* scale, float* shift, void* stream);
+int fusg_ln_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+                           const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
 /* ---- elementwise / data movement ------------------------------------------------------------ */
 
