@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfusg.so")
+LIB_PATH = os.environ.get("FUSG_LIB", os.path.join(_HERE, "libfusg.so"))   # FUSG_LIB: kernel-development override
 
 
 class FusgUnavailable(RuntimeError):

@@ -1,5 +1,6 @@
 // Host side of the fused implicit-GEMM convolution: descriptor validation, tile / split-K
 // heuristics, launch, and the deterministic split-K slab reduction.  Kernel: conv_kernel.h.
+#include <mutex>
 #include "conv_kernel_halo.h"
 
 namespace fusg {
@@ -34,6 +35,22 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK p, int nph
 
 struct TileCfg { int bm, bn; };
 static const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {128, 32}, {64, 64}, {64, 128}};
+
+// 256 zero bytes per device, allocated on first use (see ConvK::zeros)
+static const float* zero_line() {
+    static std::mutex mu;
+    static float* z[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!z[dev]) {
+        float* q = nullptr;
+        if (hipMalloc((void**)&q, 256) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, 256) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        z[dev] = q;
+    }
+    return z[dev];
+}
 
 static int64_t plan_impl(fusg_conv_desc* d) {
     const long M = (long)d->src0.n * d->qh * d->qw;
@@ -154,6 +171,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     if (d->res0.data) { k.res0 = (const float*)d->res0.data; k.r0n = d->res0.sn; k.r0c = d->res0.sc; k.r0h = d->res0.sh; k.r0w = d->res0.sw; }
     if (d->res1.data) { k.res1 = (const float*)d->res1.data; k.r1n = d->res1.sn; k.r1c = d->res1.sc; k.r1h = d->res1.sh; k.r1w = d->res1.sw; }
     k.ws = d->workspace;
+    k.zeros = zero_line();
+    if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
     k.wpack_h = (const _Float16*)d->wpack_h;
     k.H = (int)x0.h; k.W = (int)x0.w; k.ups = d->upsample; k.Hv = k.H << k.ups; k.Wv = k.W << k.ups;
     k.Cs0 = (int)x0.sw; k.Cs1 = has1 ? (int)d->src1.sw : (int)x0.sw; k.C0 = d->c0k;
@@ -211,17 +230,18 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.c = k;
         h.kh = d->kh; h.kw = d->kw; h.dil = d->dil; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
         h.stride = d->stride;
-        h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
-        h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
         h.wfrag = (const _Float16*)d->wfrag;
         h.nt32 = d->cout_pad / 32;
         int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
         if (const char* ev = getenv("FUSG_HALO_BN")) { const int v = atoi(ev); if ((v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v; }
-        h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
+        h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
+        h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
+        h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
+        h.c.MT = (int)x0.n * h.tiles_per_img;
         const int HP = h.HH * h.HW;
-        if (HP * 4 <= 2560 && (size_t)(2 * HP * (HP * 8 > 2560 ? 24 : 40)) * 2 <= 96 * 1024) {
+        if ((HP * (halo_ch16(HP) ? 4 : 8) + 255) / 256 <= 10 && halo_lds_bytes(h.HH, h.HW) <= 96 * 1024) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }

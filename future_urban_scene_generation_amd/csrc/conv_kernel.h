@@ -51,6 +51,10 @@ struct ConvK {
     int vec_epi;             // destination / residuals allow 16-byte channel-contiguous epilogue accesses
     float* stats;            // optional fused norm statistics: [B][stats_slots][Cout][2] = (mean, M2) per 32-pixel slot
     int stats_slots;         // slots per image = qh*qw/32
+    const float* zeros;      // 256 B of zeros in device memory: where the gather of a zero-padded pixel reads.  It
+                             // comes in through the kernel arguments so that the selected pointer stays a GLOBAL
+                             // one (a select against the address of a __device__ variable degrades the load to
+                             // flat_load, and every s_waitcnt after a flat load has to drain vmcnt AND lgkmcnt to 0)
 };
 
 enum { PK_NONE = 0, PK_ELU = 1, PK_AFFINE = 2 };   // compile-time pre-op kind

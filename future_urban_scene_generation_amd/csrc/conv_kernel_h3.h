@@ -45,9 +45,7 @@ __device__ __forceinline__ void split4(const f32x4 v, float lo_bound, h4& hi, h4
     lo = __builtin_bit_cast(h4, lp);
 }
 
-// 16 zero bytes: out-of-image lanes of the pre-op kinds with f(0) = 0 read this instead of being
-// masked after the load.
-__device__ const f32x4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
+// Out-of-image lanes of the pre-op kinds with f(0) = 0 read ConvK::zeros instead of being masked after the load.
 
 // 1 MFMA : FUSG_VALU_PER_MFMA VALU instruction groups for the LLVM scheduler (cdna_hip_programming.md T19)
 #ifndef FUSG_VALU_PER_MFMA
@@ -183,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             }
             const float* ptr = base + off;
             if (PK == PK_AFFINE) { ptr = ok ? ptr : base; okmask |= (ok ? 1u : 0u) << i; }
-            else ptr = ok ? ptr : (const float*)&g_zero16;      // relu(0) = elu(0) = 0: no masking needed
+            else ptr = ok ? ptr : p.zeros;                      // relu(0) = elu(0) = 0: no masking needed
             areg[i] = *(const f32x4*)ptr;
         }
 #pragma unroll

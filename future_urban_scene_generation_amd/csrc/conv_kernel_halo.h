@@ -33,6 +33,7 @@ struct HaloK {
     ConvK c;
     int kh, kw, dil, pad_h, pad_w;
     int HH, HW;                 // halo extent in (virtual) input pixels
+    int RP;                     // LDS pitch of a halo row in halves (halo_row_pitch)
     int tiles_x, tiles_per_img;
     int c1k;                    // K-channels of src1 (0 if absent)
     int stride;                 // 1 or 2 (stride-2 layers stage 16-channel chunks: their halo is ~4x larger)
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     static_assert(BM == 128 && WM * WN == 4, "8x16 pixel patch, 4 waves");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int HP = hk.HH * hk.HW;
-    _Float16* Ah = smem_h;                         // [HP][HPITCH]
-    _Float16* Al = Ah + HP * HPITCH;
+    _Float16* Ah = smem_h;                         // [HH][RP]: rows of HW pixels x HPITCH halves (+ row padding)
+    _Float16* Al = Ah + hk.HH * hk.RP;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
 
     // ---- halo items of this thread: pixel index inside the source image + validity (same for every chunk)
     int hpix[NI];                                   // iy * W + ix of the (reflected / clamped) source pixel
+    int hoff[NI];                                   // LDS offset (halves) of the item
     unsigned hvalid = 0;                            // bit j: item j is inside the image (zero padding)
     unsigned hexist = 0;                            // bit j: item j is a real halo item (j-th pass may overrun HP)
 #pragma unroll
@@ -94,9 +96,11 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         const int item = t + 256 * j;
         const int pix = item >> LOGC;
         hpix[j] = 0;
+        hoff[j] = 0;
         if (pix < HP) {
             hexist |= 1u << j;
             const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
+            hoff[j] = hy * hk.RP + hx * HPITCH + kc * 4;
             int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
             bool ok = true;
             if (p.pad_mode == FUSG_PAD_REFLECT) {
@@ -117,7 +121,6 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     const int nch0 = p.C0 / CH, nch = nch0 + hk.c1k / CH;
     const int nch32 = (p.C0 + hk.c1k) >> 5;
     const int ntaps = hk.kh * hk.kw;
-    const int ctot = p.C0 + hk.c1k;
     const int total = nch * ntaps;
 
     f32x4 hreg[NI];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float* ptr = base + (img_pix0 + hpix[j]) * Cs + coff;
-            if (PK != PK_AFFINE) ptr = ((hvalid >> j) & 1u) ? ptr : (const float*)&g_zero16;
+            if (PK != PK_AFFINE) ptr = ((hvalid >> j) & 1u) ? ptr : p.zeros;
             hreg[j] = *(const f32x4*)ptr;
         }
     };
@@ -155,9 +158,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             h4 hi, lo;
             split4(v, lo_bound, hi, lo);
             if ((hexist >> j) & 1u) {
-                const int pix = (t + 256 * j) >> LOGC;
-                *(h4*)(Ah + pix * HPITCH + kc * 4) = hi;
-                *(h4*)(Al + pix * HPITCH + kc * 4) = lo;
+                *(h4*)(Ah + hoff[j]) = hi;
+                *(h4*)(Al + hoff[j]) = lo;
             }
         }
     };
@@ -189,11 +191,11 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wm * TM * 32 + i * 32 + (lane & 31);
-        abase[i] = ((row >> 4) * hk.stride * hk.HW + (row & 15) * hk.stride) * HPITCH + (lane >> 5) * 8;
+        abase[i] = (row >> 4) * hk.stride * hk.RP + (row & 15) * hk.stride * HPITCH + (lane >> 5) * 8;
     }
     auto compute = [&](int tap, const BFrag& F) {
         const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
-        const int toff = (ky * hk.dil * hk.HW + kx * hk.dil) * HPITCH;
+        const int toff = ky * hk.dil * hk.RP + kx * hk.dil * HPITCH;
 #pragma unroll
         for (int c = 0; c < NC16; ++c) {
             h8 ah[TM], al[TM];
@@ -279,14 +281,25 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         }
 }
 
+// Staging shape of a halo of HP pixels: 32-channel chunks while every thread holds at most 10 16-byte items,
+// else (the ~4x larger stride-2 halos) 16-channel chunks.
+inline bool halo_ch16(int HP) { return HP * 8 > 2560; }
+// LDS pitch of one halo row in halves.  Stride-1 layers (32-channel chunks, 80-byte pixels): rounded up to a
+// multiple of 256 B.  A ds_read_b128 is served in groups of 16 lanes that hold pixels {0-3, 12-15} of one patch
+// row and {4-11} of the next (MI355X_MICROARCH.md, LDS); consecutive 80-byte pixels already spread over the 64
+// banks, so a group is conflict-free exactly when the two rows sit a multiple of 256 B apart (measured with the
+// natural pitch: 47 % of the LDS cycles were bank-conflict replays).
+inline int halo_row_pitch(int HW, bool ch16) { return ch16 ? HW * 24 : (HW * 40 + 127) / 128 * 128; }
+inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_pitch(HW, halo_ch16(HH * HW)) * sizeof(_Float16); }
+
 template <int TM, int TN, int WM, int WN>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
-    constexpr int BN = 32 * TN * WN;
     const int HP = k.HH * k.HW;
-    const bool ch16 = HP * 8 > 2560;                  // big (stride-2) halos are staged 16 channels at a time
-    size_t lds = (size_t)(2 * HP * (ch16 ? 24 : 40)) * sizeof(_Float16);
+    const bool ch16 = halo_ch16(HP);
+    size_t lds = halo_lds_bytes(k.HH, k.HW);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
     const int ni = (HP * (ch16 ? 4 : 8) + 255) / 256;
+    if (ni > 10 || lds > 96 * 1024) return hipErrorInvalidValue;
     const void* fn = nullptr;
 #define FUSG_PICK_NI(PKV)                                                                         \
     if (ch16) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 16>;                          \
@@ -298,6 +311,7 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     HaloK kk = k;
+    kk.RP = halo_row_pitch(k.HW, ch16);
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
