@@ -115,8 +115,9 @@ _WS = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    """Stream-ordered split-K scratch, grown on demand (one per device)."""
-    key = str(device)
+    """Stream-ordered split-K scratch, grown on demand (one per device and stream: branches of the crop pass
+    run concurrently on their own streams)."""
+    key = (str(device), stream_ptr())
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((max(nbytes, 1 << 22) + 3) // 4, device=device, dtype=torch.float32)

@@ -86,28 +86,66 @@ class VehiclePipeline:
         for n in nets:
             n.to(self.device).eval()
 
+    # The networks of one crop pass do not depend on each other (hourglass / ICN / VUnet; edge -> inpaint is one
+    # chain), so each branch runs on its own HIP stream: the many small, latency-bound launches of the hourglass
+    # and of the VUnet's low-resolution levels fill the CUs the big ICN layers leave idle between their waves of
+    # workgroups.  FUSG_STREAMS=0 serialises everything on the caller's stream.
+    def _branches(self, jobs):
+        """jobs: list of zero-argument callables returning a dict of output tensors."""
+        out = {}
+        if os.environ.get("FUSG_STREAMS", "1") == "0" or self.device.type != "cuda" or len(jobs) == 1:
+            for j in jobs:
+                out.update(j())
+            return out
+        main = torch.cuda.current_stream(self.device)
+        pool = self.__dict__.setdefault("_streams", [])
+        while len(pool) < len(jobs) - 1:
+            pool.append(torch.cuda.Stream(device=self.device))
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for i, j in enumerate(jobs):
+            if i == 0:
+                out.update(j())                                    # first branch stays on the caller's stream
+                continue
+            st = pool[i - 1]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                res = j()
+            for t in res.values():
+                t.record_stream(main)
+            out.update(res)
+        for st in pool[: len(jobs) - 1]:
+            main.wait_stream(st)
+        return out
+
     @torch.no_grad()
     def run(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """batch: 'hg_x' [B,3,R,R], 'icn_x' [B,21,R,R], 'vu_x' [B,6,R,R], 'vu_y' [B,3,R,R]
         (+ 'ec_img','ec_gray','ec_edge','ec_mask' with inpaint).  All device-resident.
         Returns 'kp_idx' int32 [B,12], 'icn_u8' / 'vunet_u8' uint8 [B,R,R,3] (+ 'inpaint_u8')."""
         from . import ops
-        out = {}
-        hm = self.hg(batch["hg_x"])["heatmaps"][-1]
-        out["kp_idx"] = ops.argmax_hw(hm)
-        out["icn_u8"] = ops.to_image_u8(self.icn(batch["icn_x"]))
-        vu = self.vunet
-        eo, es = vu.forward_enc_up(batch["vu_x"])                  # trajectory_inference.py:230-233
-        mu_app, _ = vu.forward_enc_down(eo, es)
-        do, ds = vu.forward_dec_up(batch["vu_y"])
-        xt, _, _ = vu.forward_dec_down(do, ds, mu_app)
-        out["vunet_u8"] = ops.to_image_u8(xt)
-        if self.inpaint:
+
+        def hg():
+            return {"kp_idx": ops.argmax_hw(self.hg(batch["hg_x"])["heatmaps"][-1])}
+
+        def icn():
+            return {"icn_u8": ops.to_image_u8(self.icn(batch["icn_x"]))}
+
+        def vunet():
+            vu = self.vunet
+            eo, es = vu.forward_enc_up(batch["vu_x"])                  # trajectory_inference.py:230-233
+            mu_app, _ = vu.forward_enc_down(eo, es)
+            do, ds = vu.forward_dec_up(batch["vu_y"])
+            xt, _, _ = vu.forward_dec_down(do, ds, mu_app)
+            return {"vunet_u8": ops.to_image_u8(xt)}
+
+        def inpaint():
             e = self.edge(batch["ec_gray"], batch["ec_edge"], batch["ec_mask"])      # :124-129
             p = self.inp(batch["ec_img"], e, batch["ec_mask"])
-            out["inpaint_u8"] = ops.merge_u8(p, batch["ec_img"], batch["ec_mask"])
-        return out
+            return {"inpaint_u8": ops.merge_u8(p, batch["ec_img"], batch["ec_mask"])}
 
+        # the longest branch first: it stays on the caller's stream
+        return self._branches([icn, vunet, hg] + ([inpaint] if self.inpaint else []))
 
     @torch.no_grad()
     def run_clip(self, clip: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -121,18 +159,25 @@ class VehiclePipeline:
         from . import ops
         V, F = clip["icn_x"].shape[:2]
         R = clip["hg_x"].shape[-1]
-        out = {"kp_idx": ops.argmax_hw(self.hg(clip["hg_x"])["heatmaps"][-1])}
-        icn = self.icn(clip["icn_x"].reshape(V * F, 21, R, R))
-        out["icn_u8"] = ops.to_image_u8(icn).view(V, F, R, R, 3)
-        vu = self.vunet
-        eo, es = vu.forward_enc_up(clip["vu_x"])
-        mu_app, _ = vu.forward_enc_down(eo, es)
-        # every frame of a vehicle conditions on that vehicle's appearance code: frame-major repeat
-        mu_rep = [m.repeat_interleave(F, dim=0) for m in mu_app]
-        do, ds = vu.forward_dec_up(clip["vu_y"].reshape(V * F, 3, R, R))
-        xt, _, _ = vu.forward_dec_down(do, ds, mu_rep)
-        out["vunet_u8"] = ops.to_image_u8(xt).view(V, F, R, R, 3)
-        return out
+
+        def hg():
+            return {"kp_idx": ops.argmax_hw(self.hg(clip["hg_x"])["heatmaps"][-1])}
+
+        def icn():
+            y = self.icn(clip["icn_x"].reshape(V * F, 21, R, R))
+            return {"icn_u8": ops.to_image_u8(y).view(V, F, R, R, 3)}
+
+        def vunet():
+            vu = self.vunet
+            eo, es = vu.forward_enc_up(clip["vu_x"])
+            mu_app, _ = vu.forward_enc_down(eo, es)
+            # every frame of a vehicle conditions on that vehicle's appearance code: frame-major repeat
+            mu_rep = [m.repeat_interleave(F, dim=0) for m in mu_app]
+            do, ds = vu.forward_dec_up(clip["vu_y"].reshape(V * F, 3, R, R))
+            xt, _, _ = vu.forward_dec_down(do, ds, mu_rep)
+            return {"vunet_u8": ops.to_image_u8(xt).view(V, F, R, R, 3)}
+
+        return self._branches([icn, vunet, hg])
 
 
 def synth_clip(vehicles: int, frames: int, res: int, device, seed: int = 0) -> Dict[str, torch.Tensor]:
