@@ -37,11 +37,65 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f3
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak (no sparsity)
 
 
+class PowerSampler:
+    """Socket power / shader clock of the card under test, sampled from sysfs hwmon while the timed steps run.
+    The big layers run at the 1400 W board limit, so this is part of reading the number."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.p = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") +
+                        glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        try:                                        # keep only the card torch is running on (PCI address match)
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [x for x in self.p if bdf in os.path.realpath(x.split("/hwmon/")[0])]
+            if mine:
+                self.p = mine[:1]
+        except Exception:
+            pass
+        self.f = [os.path.join(os.path.dirname(x), "freq1_input") for x in self.p]
+        self.samples, self._stop, self._th = [], False, None
+        self.idle = [self._read(x) for x in self.p]
+
+    @staticmethod
+    def _read(path):
+        try:
+            return int(open(path).read().strip())
+        except (OSError, ValueError):
+            return 0
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(([self._read(x) for x in self.p], [self._read(x) for x in self.f]))
+                time.sleep(0.01)
+
+        if self.p:
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is None:
+            return None
+        self._th.join()
+        if not self.samples:
+            return None
+        n = len(self.samples)
+        avg = [sum(s[0][i] for s in self.samples) / n for i in range(len(self.p))]
+        k = max(range(len(self.p)), key=lambda i: avg[i] - self.idle[i])       # the card whose power rose
+        return {"avg_w": round(avg[k] / 1e6, 1), "max_w": round(max(s[0][k] for s in self.samples) / 1e6, 1),
+                "sclk_mhz": round(sum(s[1][k] for s in self.samples) / n / 1e6), "samples": n,
+                "source": "sysfs hwmon power1/freq1 of the card under test, 10 ms period, timed steps only (the sensor averages over ~1 s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
@@ -98,22 +152,36 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    sampler = PowerSampler() if (rank == 0 and world == 1) else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler else None
     # Roofline leg: the SAME K steps again with one HIP-event pair around every conv launch, recorded on
     # the launch stream.  Kept out of the timed region above because ~460 event records per step cost
     # ~10 % of wall time; kernel durations themselves are unaffected (rocprofv3 agrees, profiles/).
+    # The branches of the pass are serialised for this leg (FUSG_STREAMS=0): kernels that share the GPU with
+    # another stream's kernels would each read longer than they are.
     prof = not args.no_prof
     if prof:
+        streams_env = os.environ.get("FUSG_STREAMS")
+        os.environ["FUSG_STREAMS"] = "0"
+        step()
+        barrier()
         ops.prof_reset()
         ops.prof_enable(True)
         for _ in range(args.steps):
             step()
         barrier()
         ops.prof_enable(False)
+        if streams_env is None:
+            del os.environ["FUSG_STREAMS"]
+        else:
+            os.environ["FUSG_STREAMS"] = streams_env
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -146,6 +214,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": kern,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "note": note,
+                    "measured": "second pass of the same K steps, branches serialised on one stream, one HIP-event pair per launch",
                     "launches_per_step": conv_launches // max(1, args.steps),
                     "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
                     "conv_ms_per_step": round(conv_ms / args.steps, 3),
@@ -206,6 +275,9 @@ def main():
                            "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         line.update(extra)
+        if power is not None:
+            line["power"] = power
+        line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
