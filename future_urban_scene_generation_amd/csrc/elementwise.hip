@@ -204,6 +204,45 @@ __global__ __launch_bounds__(256) void hshift_sum_kernel(const float* __restrict
     }
 }
 
+// Same sums for a channel pitch of up to 32 floats (a multiple of 4), staged through LDS: a block owns 256 consecutive
+// pixels of one image row, pulls their (+- pad) records in with coalesced 16-byte loads and each thread then picks
+// its cout*kw taps out of LDS (odd pitch tCs + 1 floats: conflict-free).  The direct kernel above reads 4 bytes
+// per lane at a 128-byte lane stride - every load instruction touches 64 cache lines.
+__global__ __launch_bounds__(256) void hshift_sum_lds_kernel(const float* __restrict__ t, int tCs, const float* __restrict__ bias,
+                                                             int kw, int pad, int reflect, int act, T4 d, int segs) {
+    extern __shared__ float tile[];               // [256 + 2*pad][tCs + 1]
+    const int q4 = tCs >> 2, lp = tCs + 1;
+    const int W = (int)d.w;
+    const long row = blockIdx.x / segs;           // b*H + y
+    const int x0 = (blockIdx.x % segs) * 256;
+    const int npx = 256 + 2 * pad;
+    for (int it = threadIdx.x; it < npx * q4; it += 256) {
+        const int p = it / q4, q = it - p * q4;
+        const int gx = x0 - pad + p;
+        if ((unsigned)gx < (unsigned)W) {
+            const float4 v = *(const float4*)(t + ((row * W + gx) * tCs + q * 4));
+            float* o = tile + p * lp + q * 4;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= W) return;
+    const long y = row % d.h, b = row / d.h;
+    float* dp = (float*)d.p + b * d.sn + y * d.sh + (long)x * d.sw;
+    for (int co = 0; co < (int)d.c; ++co) {
+        float acc = bias[co];
+        for (int kx = 0; kx < kw; ++kx) {
+            int xx = x + kx - pad;
+            bool ok = true;
+            if (reflect) xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+            else ok = (unsigned)xx < (unsigned)W;
+            if (ok) acc += tile[(xx - x0 + pad) * lp + co * kw + kx];
+        }
+        dp[co * d.sc] = act1(acc, act);
+    }
+}
+
 // first-occurrence argmax over H*W; one block per (b, c)
 __global__ __launch_bounds__(256) void argmax_hw_kernel(T4 x, int* __restrict__ idx) {
     __shared__ float sv[256];
@@ -382,6 +421,15 @@ extern "C" int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t 
     FUSG_CHECK(kw >= 1 && kw <= 15 && pad >= 0 && pad < dst->w && dst->c * kw <= t->c, "hshift_sum: kw %d pad %d cout %ld tc %ld", kw, pad, (long)dst->c, (long)t->c);
     FUSG_CHECK(act >= 0 && act <= FUSG_ACT_TANH01 && (pad_mode == 0 || pad_mode == 1), "hshift_sum: act/pad_mode");
     const long total = dst->n * dst->h * dst->w;
+    if (t->sw % 4 == 0 && t->sw <= 32 && pad <= 16 && dst->w > 2 * pad && (((uintptr_t)t->data) & 15) == 0) {
+        const int segs = (int)((dst->w + 255) / 256);
+        const long nblk = dst->n * dst->h * segs;
+        FUSG_CHECK(nblk < (1L << 31), "hshift_sum: grid too large");
+        hipLaunchKernelGGL(hshift_sum_lds_kernel, dim3((unsigned)nblk), dim3(256),
+                           (size_t)(256 + 2 * pad) * (t->sw + 1) * sizeof(float), (hipStream_t)stream, (const float*)t->data, (int)t->sw, bias, kw, pad, pad_mode, act, view(*dst), segs);
+        FUSG_LAUNCH_CHECK("hshift_sum");
+        return FUSG_OK;
+    }
     hipLaunchKernelGGL(hshift_sum_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)t->data,
                        (int)t->sw, bias, kw, pad, pad_mode, act, view(*dst), total);
     FUSG_LAUNCH_CHECK("hshift_sum");
