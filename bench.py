@@ -134,10 +134,12 @@ def main():
     pipe = VehiclePipeline(dev, inpaint=args.inpaint)
     batch = synth_batch(args.batch, args.res, dev, inpaint=args.inpaint, seed=rank)
     n_total = args.batch * world
-    torch.manual_seed(1000 + rank)                      # per-rank noise stream
+    # VUnet noise: one stream per vehicle, seeded by the vehicle's global index, so that the images do not depend
+    # on how the vehicles are spread over ranks
+    seeds = [1000 + rank * args.batch + i for i in range(args.batch)]
 
     def step():
-        out = pipe.run(batch)
+        out = pipe.run(batch, vehicle_seeds=seeds)
         if world > 1:                                   # the path's only exchange: crops -> rank 0
             crops = torch.cat([out["icn_u8"], out["vunet_u8"]], dim=-1)
             gather_in_order(crops, n_total)

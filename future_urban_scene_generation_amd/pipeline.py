@@ -119,11 +119,14 @@ class VehiclePipeline:
         return out
 
     @torch.no_grad()
-    def run(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
         """batch: 'hg_x' [B,3,R,R], 'icn_x' [B,21,R,R], 'vu_x' [B,6,R,R], 'vu_y' [B,3,R,R]
         (+ 'ec_img','ec_gray','ec_edge','ec_mask' with inpaint).  All device-resident.
-        Returns 'kp_idx' int32 [B,12], 'icn_u8' / 'vunet_u8' uint8 [B,R,R,3] (+ 'inpaint_u8')."""
+        Returns 'kp_idx' int32 [B,12], 'icn_u8' / 'vunet_u8' uint8 [B,R,R,3] (+ 'inpaint_u8').
+        vehicle_seeds: one VUnet noise seed per sample (e.g. base + global vehicle index) - makes the result of
+        a vehicle independent of how the vehicles are sharded over ranks; None = the reference's global RNG."""
         from . import ops
+        self.vunet.set_vehicle_seeds(vehicle_seeds)
 
         def hg():
             return {"kp_idx": ops.argmax_hw(self.hg(batch["hg_x"])["heatmaps"][-1])}
@@ -148,7 +151,7 @@ class VehiclePipeline:
         return self._branches([icn, vunet, hg] + ([inpaint] if self.inpaint else []))
 
     @torch.no_grad()
-    def run_clip(self, clip: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
         """Clip mode = what traj_test does per vehicle over a 6-frame clip: 1x hourglass,
         F x ICN, 1x VUnet appearance half, F x VUnet shape half with the frame-0 appearance code reused
         (trajectory_inference.py:75-79, 182, 387-391, 230-233, 424-426) - but batched over vehicles AND
@@ -169,8 +172,11 @@ class VehiclePipeline:
 
         def vunet():
             vu = self.vunet
+            vu.set_vehicle_seeds(vehicle_seeds)                   # appearance half: one stream per vehicle
             eo, es = vu.forward_enc_up(clip["vu_x"])
             mu_app, _ = vu.forward_enc_down(eo, es)
+            if vehicle_seeds is not None:                         # shape half: one stream per (vehicle, frame)
+                vu.set_vehicle_seeds([int(sd) * 64 + f + 1 for sd in vehicle_seeds for f in range(F)])
             # every frame of a vehicle conditions on that vehicle's appearance code: frame-major repeat
             mu_rep = [m.repeat_interleave(F, dim=0) for m in mu_app]
             do, ds = vu.forward_dec_up(clip["vu_y"].reshape(V * F, 3, R, R))

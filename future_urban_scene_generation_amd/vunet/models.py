@@ -185,6 +185,43 @@ class Vunet_fix_res(FusedNet):
     def _upsample(self, name: str, x):
         return ops.conv(self._plans[name + ".depth4x"], x, store=L.STORE_D2S)
 
+    def set_vehicle_seeds(self, seeds=None):
+        """Optional, beyond the reference: give every sample of the next passes its own noise stream
+        (`torch.Generator` seeded per vehicle, consumed in the reference's sampler order) instead of the
+        shared global CPU generator.  A vehicle's noise then does not depend on which other vehicles share
+        its batch, so a clip sharded over N GPUs renders the same images as on one (noise
+        caveat).  `None` restores the reference behaviour (global generator, batch-shaped draws)."""
+        if seeds is None:
+            self.__dict__.pop("_vehicle_gens", None)
+            return
+        gens = []
+        for sd in seeds:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(int(sd))
+            gens.append(g)
+        self.__dict__["_vehicle_gens"] = gens
+
+    @staticmethod
+    def _fill_noise(buf, shapes, gens=None):
+        """Writes the N(0,1) draws for `shapes` (in order) into the flat host buffer `buf`; returns
+        [(offset, numel, shape)].  gens=None: `torch.randn(*shape)` on the global CPU generator, exactly the
+        reference's draw (layers.py:166).  Else one generator per sample: sample b of every shape comes from
+        gens[b], in shape order."""
+        off, views = 0, []
+        for s in shapes:
+            n = int(torch.Size(s).numel())
+            v = buf[off:off + n].view(*s)
+            if gens is None:
+                torch.randn(*s, out=v)                              # == torch.randn(*s): same stream, same values
+            else:
+                if len(gens) != s[0]:
+                    raise ValueError(f"set_vehicle_seeds: {len(gens)} seeds for a batch of {s[0]}")
+                for b, g in enumerate(gens):
+                    torch.randn(*s[1:], out=v[b], generator=g)
+            views.append((off, n, s))
+            off += n
+        return views
+
     def _draw_noise(self, shapes, device):
         """All Sampler draws of one entry point, up front: same CPU default generator, same shapes,
         same order as the reference's `torch.randn(*mu.size())` calls (layers.py:166), but written
@@ -202,13 +239,7 @@ class Vunet_fix_res(FusedNet):
             ev.synchronize()                                        # copy issued 4 calls ago: long done
         if buf is None or buf.numel() < total:
             buf = torch.empty(max(total, 1 << 16), dtype=torch.float32, pin_memory=True)
-        off, views = 0, []
-        for s in shapes:
-            n = int(torch.Size(s).numel())
-            v = buf[off:off + n].view(*s)
-            torch.randn(*s, out=v)                                  # == torch.randn(*s): same stream, same values
-            views.append((off, n, s))
-            off += n
+        views = self._fill_noise(buf, shapes, self.__dict__.get("_vehicle_gens"))
         dev_buf = buf[:total].to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

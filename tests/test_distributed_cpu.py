@@ -74,3 +74,36 @@ def test_gather_in_vehicle_order(world, n_items):
 def test_single_process_is_identity():
     x = _fake_render([0, 1, 2])
     assert gather_in_order(x, 3) is x
+
+
+def test_vehicle_noise_streams_are_shard_invariant():
+    """Host half of the 8(e) noise caveat: with one generator per vehicle the draws of vehicle v are the
+    same whatever batch it sits in; without (reference mode) they are `torch.randn(*shape)` on the global RNG."""
+    from future_urban_scene_generation_amd.vunet.models import Vunet_fix_res
+
+    def gens(seeds):
+        out = []
+        for sd in seeds:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(sd)
+            out.append(g)
+        return out
+
+    def draw(seeds, B):
+        shapes = [(B, 128, 2, 2)] * 2 + [(B, 128, 4, 4)]
+        buf = torch.empty(sum(int(torch.Size(s).numel()) for s in shapes))
+        views = Vunet_fix_res._fill_noise(buf, shapes, gens(seeds) if seeds else None)
+        return [buf[o:o + n].view(*s).clone() for o, n, s in views]
+
+    full = draw([10, 11, 12, 13], 4)
+    for lo, hi in (shard_range(4, 0, 2), shard_range(4, 1, 2)):
+        part = draw([10 + i for i in range(lo, hi)], hi - lo)
+        for f, p in zip(full, part):
+            assert torch.equal(f[lo:hi], p)
+    torch.manual_seed(5)
+    ref = [torch.randn(2, 128, 2, 2), torch.randn(2, 128, 2, 2), torch.randn(2, 128, 4, 4)]
+    torch.manual_seed(5)
+    got = draw(None, 2)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    with pytest.raises(ValueError):
+        draw([1, 2, 3], 2)
