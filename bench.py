@@ -119,10 +119,18 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if os.environ.get("FUSG_DIST_BACKEND", "nccl") != "nccl":          # rehearsal: ranks share the cards that exist
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL ("nccl" on ROCm).  FUSG_DIST_BACKEND=gloo rehearses the multi-rank code path where the ranks have
+        # to share one card (development boxes): the gathers are then staged through host memory.
+        backend = os.environ.get("FUSG_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from future_urban_scene_generation_amd import ops
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, synth_batch
@@ -184,7 +192,7 @@ def main():
             del os.environ["FUSG_STREAMS"]
         else:
             os.environ["FUSG_STREAMS"] = streams_env
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -39,6 +39,8 @@ def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_range(n_items, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in sizes)
+    if local.is_cuda and dist.get_backend(group) == "gloo":       # rehearsal of the multi-rank path without RCCL
+        local = local.cpu()
     pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
