@@ -41,12 +41,13 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
                 ("wpack_h", C.c_void_p),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("_pad2", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p)]
+                ("_pad2", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
+                ("tile_list", C.c_void_p), ("tile_count", C.c_int32), ("_pad3", C.c_int32)]
 
 
 # enums (include/fusg.h)
 F32, U8, I32 = 0, 1, 2
-PAD_ZERO, PAD_REFLECT = 0, 1
+PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 PRE_NONE, PRE_RELU, PRE_ELU, PRE_AFFINE_RELU, PRE_AFFINE = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_TANH01 = 0, 1, 2, 3, 4
 STORE_NORMAL, STORE_D2S, STORE_S2D = 0, 1, 2

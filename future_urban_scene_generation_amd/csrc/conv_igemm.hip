@@ -113,7 +113,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     FUSG_CHECK(d->c0k >= 0 && d->c0k % 4 == 0 && d->c0k <= x0.sw, "conv2d: bad c0k %d (src0 Cs %ld)", d->c0k, (long)x0.sw);
     FUSG_CHECK(d->stride == 1 || d->stride == 2, "conv2d: stride %d", d->stride);
     FUSG_CHECK(d->upsample == 0 || d->upsample == 1, "conv2d: upsample %d", d->upsample);
-    FUSG_CHECK(d->pad_mode == FUSG_PAD_ZERO || d->pad_mode == FUSG_PAD_REFLECT, "conv2d: pad_mode");
+    FUSG_CHECK(d->pad_mode == FUSG_PAD_ZERO || d->pad_mode == FUSG_PAD_REFLECT || d->pad_mode == FUSG_PAD_REPLICATE, "conv2d: pad_mode");
+    FUSG_CHECK(!d->tile_list || (d->tile_count > 0 && !d->stats_out), "conv2d: tile_list needs tile_count > 0 and no stats_out");
     FUSG_CHECK(d->pre_op >= 0 && d->pre_op <= FUSG_PRE_AFFINE, "conv2d: pre_op");
     FUSG_CHECK(d->act >= 0 && d->act <= FUSG_ACT_TANH01, "conv2d: act");
     if (d->pre_op >= FUSG_PRE_AFFINE_RELU) {
@@ -240,6 +241,11 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c.MT = (int)x0.n * h.tiles_per_img;
+        if (d->tile_list) {
+            if (d->tile_count > h.tiles_per_img) { set_error("conv2d: tile_count %d > %d patches per image", d->tile_count, h.tiles_per_img); return FUSG_ERR_INVALID; }
+            h.tile_list = d->tile_list; h.tile_count = d->tile_count;
+            h.c.MT = (int)x0.n * d->tile_count;
+        }
         const int HP = h.HH * h.HW;
         if ((HP * (halo_ch16(HP) ? 4 : 8) + 255) / 256 <= 10 && halo_lds_bytes(h.HH, h.HW) <= 96 * 1024) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
@@ -248,6 +254,11 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
             prof_end(0, s);
             return FUSG_OK;
         }
+    }
+    if (d->tile_list || d->pad_mode == FUSG_PAD_REPLICATE) {
+        set_error("conv2d: tile_list / PAD_REPLICATE need a launch that qualifies for the halo kernel");
+        prof_end(0, s);
+        return FUSG_ERR_UNSUPPORTED;
     }
     if (d->precision == FUSG_PREC_F16X3) {
         switch (d->tile) {

@@ -38,6 +38,8 @@ struct HaloK {
     int c1k;                    // K-channels of src1 (0 if absent)
     int stride;                 // 1 or 2 (stride-2 layers stage 16-channel chunks: their halo is ~4x larger)
     const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
+    const int* tile_list;       // optional: patch indices (within an image) to compute; MT = B * tile_count
+    int tile_count;
     int nt32;                   // cout_pad / 32
 };
 
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     }
     const int nt = tile % p.NT;
     const int mt = tile / p.NT;
-    const int b = mt / hk.tiles_per_img;
-    const int t2 = mt - b * hk.tiles_per_img;
+    int b, t2;
+    if (hk.tile_list) { b = mt / hk.tile_count; t2 = hk.tile_list[mt - b * hk.tile_count]; }
+    else { b = mt / hk.tiles_per_img; t2 = mt - b * hk.tiles_per_img; }
     const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
     const int oy0 = ty * 8, ox0 = tx * 16;
 
@@ -106,6 +109,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             if (p.pad_mode == FUSG_PAD_REFLECT) {
                 vy = vy < 0 ? -vy : (vy >= p.Hv ? 2 * p.Hv - 2 - vy : vy);
                 vx = vx < 0 ? -vx : (vx >= p.Wv ? 2 * p.Wv - 2 - vx : vx);
+            } else if (p.pad_mode == FUSG_PAD_REPLICATE) {
+                vy = min(max(vy, 0), p.Hv - 1);
+                vx = min(max(vx, 0), p.Wv - 1);
             } else {
                 ok = (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv;
             }

@@ -129,9 +129,13 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
          out_c_off: int = 0, res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
          pre_op: int = L.PRE_NONE, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_bstride: int = 0,
          act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
-         ksplit: int = 0, precision: Optional[str] = None, want_stats: bool = False):
+         ksplit: int = 0, precision: Optional[str] = None, want_stats: bool = False,
+         out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), tiles: Optional[torch.Tensor] = None):
     """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
-    unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result)."""
+    unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result).
+    out_stride / out_off: write output pixel (qy, qx) at (qy*out_stride + out_off[0], qx*out_stride + out_off[1])
+    of `out` (phase launches).  tiles: int32 device tensor of 8x16-pixel patch indices - compute only those
+    (halo-kernel launches only)."""
     plan.to(x0.device)
     b, c0, h, w = x0.shape
     assert c0 == plan.c_split[0], (x0.shape, plan.c_split)
@@ -176,7 +180,12 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
             d.out_oy[ph] = ph >> 1
             d.out_ox[ph] = ph & 1
     else:
-        d.out_sy = d.out_sx = 1
+        assert out_stride == 1 or (out is not None and store == L.STORE_NORMAL)
+        d.out_sy = d.out_sx = int(out_stride)
+        d.out_oy[0], d.out_ox[0] = int(out_off[0]), int(out_off[1])
+    if tiles is not None:
+        assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.device == x0.device
+        d.tile_list, d.tile_count = tiles.data_ptr(), int(tiles.numel())
     d.dst_c_off = int(out_c_off)
     d.tile, d.ksplit = int(tile), int(ksplit)
     d.precision = _PREC[precision or PRECISION]
@@ -203,6 +212,46 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
             d.stats_out = stats.data_ptr()
     L.check(lib.fusg_conv2d(C.byref(d), stream_ptr()), "conv2d")
     return (out, stats) if want_stats else out
+
+
+_BORDER_TILES = {}
+
+
+def border_tiles(h: int, w: int, device) -> torch.Tensor:
+    """Indices of the 8x16-pixel patches of an h x w image that touch its border (row-major patch grid)."""
+    key = (h, w, str(device))
+    t = _BORDER_TILES.get(key)
+    if t is None:
+        ny, nx = h // 8, w // 16
+        idx = [y * nx + x for y in range(ny) for x in range(nx) if y in (0, ny - 1) or x in (0, nx - 1)]
+        t = torch.tensor(idx, dtype=torch.int32, device=device)
+        _BORDER_TILES[key] = t
+    return t
+
+
+def up2_phases_ok(x: torch.Tensor, precision: Optional[str] = None) -> bool:
+    """Does `conv_up2` take the 4-phase route for this input?  (All five launches must qualify for the halo kernel.)"""
+    b, c, h, w = x.shape
+    return ((precision or PRECISION) == "f16x3" and c % 32 == 0 and h % 8 == 0 and w % 16 == 0 and h >= 8 and w >= 16
+            and _os.environ.get("FUSG_NO_HALO") is None and _os.environ.get("FUSG_NO_UP2_PHASES") is None)
+
+
+def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
+             precision: Optional[str] = None) -> torch.Tensor:
+    """nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv.  `exact` = the 25-tap plan with the upsample fused into its
+    gather (pack_conv(..., upsample=1)); `phases` = pack_conv_up2_phases of the same filter.  When the shapes qualify,
+    four 3x3 phase launches on the low-res input (9 MACs per output instead of 25) write the interleaved output and
+    the 25-tap form then recomputes the border patches, the only place the two differ (pack.up2_phase_weights)."""
+    if phases is None or not up2_phases_ok(x, precision):
+        return conv(exact, x, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)
+    b, c, h, w = x.shape
+    out = nhwc_empty(b, exact.cout, 2 * h, 2 * w, x.device)
+    for ph, plan in enumerate(phases):                              # ksplit=1: split-K launches do not use the halo kernel
+        conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
+             precision=precision, ksplit=1)
+    conv(exact, x, out=out, tiles=border_tiles(2 * h, 2 * w, x.device), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
+         precision=precision, ksplit=1)
+    return out
 
 
 def conv_rowsplit(plan: ConvPlan, x0: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,

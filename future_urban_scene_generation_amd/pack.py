@@ -9,7 +9,7 @@ that drives the on-the-fly im2col gather (see include/fusg.h, ``fusg_conv_desc``
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Optional, Sequence, Tuple
+from typing import List,  Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -152,6 +152,43 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], *, c_split: Op
     return ConvPlan(wpack=panel[None].contiguous(), bias=b, ktab=tab[None].contiguous(), cout=cout, cout_pad=cout_pad,
                     k_pad=k_pad, c_split=c_split, c0k=c0k, c1k=c1k, kh=kh, kw=kw, stride=stride, pad=pad, dil=dil,
                     pad_mode=pad_mode, upsample=upsample, nphase=1, flops_per_pixel=2.0 * cout * cin * kh * kw)
+
+
+UP2_GROUPS = (((0, 1), (2, 3), (4,)), ((0,), (1, 2), (3, 4)))     # per output parity: 5 taps -> low-res rows -1, 0, +1
+
+
+def up2_phase_weights(weight: torch.Tensor) -> List[torch.Tensor]:
+    """nn.Upsample(2, nearest) -> 5x5 conv (pad 2), seen from the low-resolution side.  Output pixel
+    (2y+py, 2x+px) reads upsampled rows 2y+py-2 .. 2y+py+2, i.e. low-res rows y-1, y, y+1 with the 5 taps
+    grouped as UP2_GROUPS[py]; the same along x.  So each of the 4 output parities is a 3x3 convolution of the
+    LOW-res image whose weights are sums of the original taps: 9 MACs per output instead of 25.  Exact in real
+    arithmetic (fp32 rounding differs like any re-association) wherever the 5-tap window stays inside the
+    upsampled image; with the reference's ReflectionPad2d(2) (warp_learn/models.py:176-178) and edge-replicate
+    padding on the low-res side it also holds on the second ring, and fails only on the outermost ring of
+    output pixels (row/col 0 and 2H-1 / 2W-1), which the caller recomputes with the 25-tap form.
+    Returns [w_00, w_01, w_10, w_11] (index 2*py+px), each [cout, cin, 3, 3]."""
+    w = weight.detach().to("cpu", torch.float32)
+    assert w.shape[2] == 5 and w.shape[3] == 5, w.shape
+    out = []
+    for py in range(2):
+        for px in range(2):
+            wp = torch.zeros(w.shape[0], w.shape[1], 3, 3, dtype=torch.float32)
+            for a, gy in enumerate(UP2_GROUPS[py]):
+                for b, gx in enumerate(UP2_GROUPS[px]):
+                    # fixed summation order (ky, then kx ascending): the packed weights are reproducible
+                    acc = torch.zeros(w.shape[0], w.shape[1], dtype=torch.float32)
+                    for ky in gy:
+                        for kx in gx:
+                            acc = acc + w[:, :, ky, kx]
+                    wp[:, :, a, b] = acc
+            out.append(wp)
+    return out
+
+
+def pack_conv_up2_phases(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> List[ConvPlan]:
+    """The four 3x3 phase convolutions of up2_phase_weights as ConvPlans (edge-replicate padding 1)."""
+    from . import _lib as L
+    return [pack_conv(wp, bias, stride=1, pad=1, pad_mode=L.PAD_REPLICATE) for wp in up2_phase_weights(weight)]
 
 
 def pack_conv_transpose_k4s2p1(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> ConvPlan:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 100
+#define FUSG_VERSION 101
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -50,7 +50,11 @@ typedef struct fusg_tensor {
 
 /* ---- convolution ------------------------------------------------------------------------- */
 
-typedef enum fusg_pad_mode { FUSG_PAD_ZERO = 0, FUSG_PAD_REFLECT = 1 } fusg_pad_mode;
+typedef enum fusg_pad_mode {
+    FUSG_PAD_ZERO = 0, FUSG_PAD_REFLECT = 1,
+    FUSG_PAD_REPLICATE = 2     /* clamp to the edge; halo-kernel launches only (the phase form of
+                                  nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv, pack.py) */
+} fusg_pad_mode;
 
 /* op applied to every in-bounds source element while the im2col tile is staged (padding stays 0) */
 typedef enum fusg_pre_op {
@@ -149,6 +153,11 @@ typedef struct fusg_conv_desc {
      * channel-contiguous 16-byte aligned dst with cout % 4 == 0 (else FUSG_ERR_UNSUPPORTED).
      * Feed to fusg_in_finalize_slots / fusg_ln_finalize_slots. */
     float*         stats_out;
+    /* Optional (halo-kernel launches only, else FUSG_ERR_UNSUPPORTED): compute only these 8 x 16-pixel
+     * patches of every image - indices into the row-major (qh/8) x (qw/16) patch grid, device memory. */
+    const int32_t* tile_list;
+    int32_t        tile_count;
+    int32_t        _pad3;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);

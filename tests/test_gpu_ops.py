@@ -133,6 +133,51 @@ def test_conv_upsample_fused():
     _close(ops.conv(plan, _nhwc(x)), ref)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 32, 64, 16, 32), (1, 64, 32, 8, 16), (2, 32, 48, 12, 16)])
+def test_conv_up2_phases(B, cin, cout, H, W, precision):
+    """Upsample(2)+reflect 5x5 through the 4-phase route (when the shape qualifies) == torch; with an affine+ReLU
+    pre-op like the ICN decoder; and the route really is taken for the qualifying shapes."""
+    x = _rand(B, cin, H, W, seed=1)
+    w = _rand(cout, cin, 5, 5, seed=2, scale=1.0 / (cin * 25) ** 0.5)
+    b = _rand(cout, seed=3)
+    sc, sh = torch.rand(B, cin, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(B, cin, seed=5) * 0.2
+    exact = pack.pack_conv(w, b, pad=2, pad_mode=1, upsample=1)
+    phases = pack.pack_conv_up2_phases(w, b)
+    xin = torch.relu(x * sc[:, :, None, None] + sh[:, :, None, None])
+    ref = F.conv2d(F.pad(F.interpolate(xin, scale_factor=2, mode="nearest"), (2,) * 4, mode="reflect"), w, b)
+    pre = (sc.to(dev()).contiguous(), sh.to(dev()).contiguous())
+    xd = _nhwc(x)
+    assert ops.up2_phases_ok(xd) == (precision == "f16x3" and H % 8 == 0 and W % 16 == 0)
+    got = ops.conv_up2(exact, phases, xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)
+    assert tuple(got.shape) == tuple(ref.shape)
+    _close(got, ref)
+
+
+def test_conv_tile_list_and_replicate_pad(precision):
+    """tile_list computes only the listed 8x16 patches; PAD_REPLICATE = edge clamp (halo-kernel launches only)."""
+    if precision != "f16x3":
+        x = _nhwc(_rand(1, 32, 16, 32, seed=1))
+        plan = pack.pack_conv(_rand(32, 32, 3, 3, seed=2) * 0.05, None, pad=1, pad_mode=L.PAD_REPLICATE)
+        with pytest.raises(RuntimeError):
+            ops.conv(plan, x)                                      # no halo kernel on the exact-fp32 path
+        return
+    x = _rand(2, 32, 24, 48, seed=1)
+    w = _rand(32, 32, 3, 3, seed=2, scale=0.05)
+    ref = F.conv2d(F.pad(x, (1,) * 4, mode="replicate"), w)
+    plan = pack.pack_conv(w, None, pad=1, pad_mode=L.PAD_REPLICATE)
+    _close(ops.conv(plan, _nhwc(x), ksplit=1), ref)                # (split-K launches do not use the halo kernel)
+    tiles = ops.border_tiles(24, 48, dev())                        # 3 x 3 patch grid: all but the centre patch
+    assert sorted(tiles.cpu().tolist()) == [0, 1, 2, 3, 5, 6, 7, 8]
+    out = ops.nhwc_empty(2, 32, 24, 48, dev())
+    out.fill_(7.0)
+    ops.conv(plan, _nhwc(x), out=out, tiles=tiles, ksplit=1)
+    got = out.cpu()
+    assert torch.all(got[:, :, 8:16, 16:32] == 7.0)
+    mask = torch.ones(24, 48, dtype=torch.bool)
+    mask[8:16, 16:32] = False
+    torch.testing.assert_close(got[:, :, mask], ref[:, :, mask], rtol=2e-4, atol=2e-4)
+
+
 def test_conv_transpose():
     x = _rand(2, 32, 7, 9, seed=1)
     w = _rand(32, 24, 4, 4, seed=2, scale=0.1)

@@ -60,6 +60,26 @@ def test_upsample_fused_reflect():
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
 
 
+def test_up2_phase_weights_identity():
+    """Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv == four 3x3 convs of the low-res image with summed taps and
+    edge-replicate padding, everywhere but on the outermost ring of output pixels (which ops.conv_up2 recomputes)."""
+    x = _rand(2, 6, 7, 9, seed=1)
+    w = _rand(5, 6, 5, 5, seed=2) * 0.1
+    b = _rand(5, seed=3)
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (2,) * 4, mode="reflect"), w, b)
+    got = torch.empty_like(ref)
+    xp = F.pad(x, (1,) * 4, mode="replicate")
+    for ph, wp in enumerate(pack.up2_phase_weights(w)):
+        got[:, :, (ph >> 1)::2, (ph & 1)::2] = F.conv2d(xp, wp, b)
+    torch.testing.assert_close(got[:, :, 1:-1, 1:-1], ref[:, :, 1:-1, 1:-1], rtol=1e-5, atol=1e-5)
+    ring = torch.ones_like(ref, dtype=torch.bool)
+    ring[:, :, 1:-1, 1:-1] = False
+    assert (got - ref)[ring].abs().max() > 1e-3          # the ring really differs: it is not optional to redo it
+    # the ConvPlans carry exactly these filters
+    plans = pack.pack_conv_up2_phases(w, b)
+    assert len(plans) == 4 and all(q.kh == 3 and q.pad == 1 and q.pad_mode == 2 and q.upsample == 0 for q in plans)
+
+
 def test_affine_relu_prologue_keeps_padding_zero():
     x = _rand(2, 8, 6, 6, seed=1)
     w = _rand(4, 8, 3, 3, seed=2)
