@@ -83,12 +83,13 @@ class PowerSampler:
         self._th.join()
         if not self.samples:
             return None
+        self.samples = self.samples[len(self.samples) // 2:]                   # the sensor lags by up to ~1 s: steady half
         n = len(self.samples)
         avg = [sum(s[0][i] for s in self.samples) / n for i in range(len(self.p))]
         k = max(range(len(self.p)), key=lambda i: avg[i] - self.idle[i])       # the card whose power rose
         return {"avg_w": round(avg[k] / 1e6, 1), "max_w": round(max(s[0][k] for s in self.samples) / 1e6, 1),
                 "sclk_mhz": round(sum(s[1][k] for s in self.samples) / n / 1e6), "samples": n,
-                "source": "sysfs hwmon power1/freq1 of the card under test, 10 ms period, timed steps only (the sensor averages over ~1 s)"}
+                "source": "sysfs hwmon power1/freq1 of the card under test, 10 ms period, second half of warm-up + timed + roofline legs"}
 
 
 def main():
@@ -159,18 +160,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
     sampler = PowerSampler() if (rank == 0 and world == 1) else None
     if sampler:
         sampler.start()
+    for _ in range(args.warmup):
+        step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    power = sampler.stop() if sampler else None
     # Roofline leg: the SAME K steps again with one HIP-event pair around every conv launch, recorded on
     # the launch stream.  Kept out of the timed region above because ~460 event records per step cost
     # ~10 % of wall time; kernel durations themselves are unaffected (rocprofv3 agrees, profiles/).
@@ -192,6 +192,7 @@ def main():
             del os.environ["FUSG_STREAMS"]
         else:
             os.environ["FUSG_STREAMS"] = streams_env
+    power = sampler.stop() if sampler else None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
