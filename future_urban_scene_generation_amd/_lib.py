@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("dst_c_off", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32), ("precision", C.c_int32),
                 ("wpack_h", C.c_void_p),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("_pad2", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
+                ("wfrag_order", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
                 ("tile_list", C.c_void_p), ("tile_count", C.c_int32), ("_pad3", C.c_int32)]
 
 
@@ -79,6 +79,7 @@ _SIGS = {
     "fusg_merge_u8": (C.c_int, [_TP, _TP, _TP, _TP, C.c_void_p]),
     "fusg_version": (C.c_int, []),
     "fusg_last_error": (C.c_char_p, []),
+    "fusg_last_conv_kernel": (C.c_int, []),
     "fusg_arch": (C.c_char_p, []),
     "fusg_sizeof_tensor": (C.c_int, []),
     "fusg_sizeof_conv_desc": (C.c_int, []),

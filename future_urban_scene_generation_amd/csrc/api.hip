@@ -61,6 +61,10 @@ using namespace fusg;
 
 extern "C" int fusg_version(void) { return FUSG_VERSION; }
 extern "C" const char* fusg_last_error(void) { return g_err; }
+
+static thread_local int g_conv_kernel = -1;
+namespace fusg { void note_conv_kernel(int kind) { g_conv_kernel = kind; } }
+extern "C" int fusg_last_conv_kernel(void) { return g_conv_kernel; }
 extern "C" const char* fusg_arch(void) { return "gfx950"; }
 extern "C" int fusg_sizeof_tensor(void) { return (int)sizeof(fusg_tensor); }
 extern "C" int fusg_sizeof_conv_desc(void) { return (int)sizeof(fusg_conv_desc); }

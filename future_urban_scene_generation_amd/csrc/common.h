@@ -9,6 +9,7 @@
 namespace fusg {
 
 void set_error(const char* fmt, ...);
+void note_conv_kernel(int kind);        // fusg_last_conv_kernel(): which kernel family the last conv launch used
 
 #define FUSG_CHECK(cond, ...)                         \
     do {                                              \

@@ -224,7 +224,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
-                         getenv("FUSG_NO_HALO") == nullptr;
+                         getenv("FUSG_NO_HALO") == nullptr &&
+                         !(d->wfrag_order == 1 && (x0.h % 2 != 0 || x0.w % 2 != 0 || d->stride != 2));   // odd sizes: generic gather
     if (halo_ok) {
         HaloK h;
         memset(&h, 0, sizeof(h));
@@ -239,6 +240,32 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
         h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
+        if (d->stride == 2 && d->wfrag_order == 1) {
+            // parity-quadrant form (include/fusg.h, wfrag_order): input row 2Y - 1 + ky = parity (ky-1)&1, sub-row Y + (ky-1 >> 1)
+            if (!(d->kh == d->kw && (d->kh == 3 || d->kh == 4) && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 && !has1 &&
+                  d->pad_mode != FUSG_PAD_REPLICATE)) {
+                set_error("conv2d: wfrag_order 1 needs stride 2, k3/k4, pad 1, dil 1, one source");
+                prof_end(0, s);
+                return FUSG_ERR_INVALID;
+            }
+            h.s2d = 1; h.stride = 1; h.HH = 10; h.HW = 18;
+            const int rp = halo_row_pitch(h.HW, false);
+            int slab = 0;
+            for (int q = 0; q < 4; ++q) {
+                h.qwoff[q] = slab;
+                int n = 0;
+                for (int ky = 0; ky < d->kh; ++ky) {
+                    if (((ky - 1) & 1) != (q >> 1)) continue;
+                    for (int kx = 0; kx < d->kw; ++kx) {
+                        if (((kx - 1) & 1) != (q & 1)) continue;
+                        const int dy = (ky - 1) >> 1, dx = (kx - 1) >> 1;          // arithmetic shift: floor
+                        h.qtoff[q][n++] = (dy + 1) * rp + (dx + 1) * 40;
+                    }
+                }
+                h.qtaps[q] = n;
+                slab += n;
+            }
+        }
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c.MT = (int)x0.n * h.tiles_per_img;
         if (d->tile_list) {
@@ -251,6 +278,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+            note_conv_kernel(h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO);
             prof_end(0, s);
             return FUSG_OK;
         }
@@ -260,6 +288,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         prof_end(0, s);
         return FUSG_ERR_UNSUPPORTED;
     }
+    note_conv_kernel(d->precision == FUSG_PREC_F16X3 ? FUSG_CONV_GENERIC_F16X3 : FUSG_CONV_GENERIC_F32);
     if (d->precision == FUSG_PREC_F16X3) {
         switch (d->tile) {
             case FUSG_TILE_128x128: e = launch_h3_128x128(k, grid, s, pk, gen); break;

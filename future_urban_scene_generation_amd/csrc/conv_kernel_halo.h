@@ -40,6 +40,12 @@ struct HaloK {
     const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
     const int* tile_list;       // optional: patch indices (within an image) to compute; MT = B * tile_count
     int tile_count;
+    // Stride-2 k3/k4 pad-1 layers as four stride-1 convolutions of the parity sub-images x[2Y+i, 2X+j] (q = 2i+j):
+    // a chunk is then (quadrant, 32 channels) with its own short tap list; LDS reads stay unit-stride.
+    int s2d;                    // 1: quadrant form (stride above is 1, HH x HW = 10 x 18 sub-image pixels)
+    int qtaps[4];               // taps of each quadrant
+    int qwoff[4];               // first weight slab of each quadrant (slabs of a quadrant are consecutive)
+    int qtoff[4][4];            // LDS offset (halves) of each (quadrant, local tap)
     int nt32;                   // cout_pad / 32
 };
 
@@ -106,6 +112,15 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             hoff[j] = hy * hk.RP + hx * HPITCH + kc * 4;
             int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
             bool ok = true;
+            if (hk.s2d) {
+                // sub-image coordinates; reflection of the full image at -1 / H is a clamp of the sub-image
+                int sy = oy0 - 1 + hy, sx = ox0 - 1 + hx;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                if (p.pad_mode == FUSG_PAD_ZERO) ok = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+                sy = min(max(sy, 0), Hs - 1); sx = min(max(sx, 0), Ws - 1);
+                if (ok) { hvalid |= 1u << j; hpix[j] = 2 * sy * p.W + 2 * sx; }
+                continue;
+            }
             if (p.pad_mode == FUSG_PAD_REFLECT) {
                 vy = vy < 0 ? -vy : (vy >= p.Hv ? 2 * p.Hv - 2 - vy : vy);
                 vx = vx < 0 ? -vx : (vx >= p.Wv ? 2 * p.Wv - 2 - vx : vx);
@@ -124,10 +139,11 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 4 * 64 + lane) * 8;
     const long wstep = (long)hk.nt32 * 4 * 64 * 8;            // halves per (tap, chunk) slab
     const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
-    const int nch0 = p.C0 / CH, nch = nch0 + hk.c1k / CH;
+    const int nchq = p.C0 / CH;                                 // chunks per quadrant (quadrant form)
+    const int nch0 = hk.s2d ? 4 * nchq : p.C0 / CH, nch = nch0 + hk.c1k / CH;
     const int nch32 = (p.C0 + hk.c1k) >> 5;
     const int ntaps = hk.kh * hk.kw;
-    const int total = nch * ntaps;
+    auto taps_of = [&](int cg) { return hk.s2d ? hk.qtaps[cg / nchq] : ntaps; };
 
     f32x4 hreg[NI];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -136,7 +152,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         const bool s1 = cg >= nch0;
         const float* base = s1 ? p.src1 : p.src0;
         const int Cs = s1 ? p.Cs1 : p.Cs0;
-        const int coff = (s1 ? cg - nch0 : cg) * CH + kc * 4;
+        int coff = (s1 ? cg - nch0 : cg) * CH + kc * 4;
+        long qpix = img_pix0;
+        if (hk.s2d) { const int q = cg / nchq; coff = (cg - q * nchq) * CH + kc * 4; qpix += (q >> 1) * p.W + (q & 1); }
         if (PK == PK_AFFINE) {
             const long o = (long)b * p.pre_bstride + (s1 ? p.C0 : 0) + coff;
             sc = *(const f32x4*)(p.pre_scale + o);
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const float* ptr = base + (img_pix0 + hpix[j]) * Cs + coff;
+            const float* ptr = base + (qpix + hpix[j]) * Cs + coff;
             if (PK != PK_AFFINE) ptr = ((hvalid >> j) & 1u) ? ptr : p.zeros;
             hreg[j] = *(const f32x4*)ptr;
         }
@@ -171,9 +189,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     };
     struct BFrag { h8 f[TN][NC16][2]; };              // [column tile][16-k chunk][hi, lo]
     BFrag bfA, bfB;
-    auto b_load = [&](BFrag& F, int step) {
-        const int cg = step / ntaps, tap = step - cg * ntaps;
-        const int k16 = cg * NC16;                                  // first 16-k chunk of this staged chunk
+    auto b_load = [&](BFrag& F, int cg, int tap) {
+        int k16 = cg * NC16;                                        // first 16-k chunk of this staged chunk
+        if (hk.s2d) { const int q = cg / nchq; tap += hk.qwoff[q]; k16 = (cg - q * nchq) * NC16; }
         const _Float16* base = wfr + (long)(tap * nch32 + (k16 >> 1)) * wstep;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -199,9 +217,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         const int row = wm * TM * 32 + i * 32 + (lane & 31);
         abase[i] = (row >> 4) * hk.stride * hk.RP + (row & 15) * hk.stride * HPITCH + (lane >> 5) * 8;
     }
-    auto compute = [&](int tap, const BFrag& F) {
+    auto compute = [&](int cg, int tap, const BFrag& F) {
         const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
-        const int toff = ky * hk.dil * hk.RP + kx * hk.dil * HPITCH;
+        const int toff = hk.s2d ? hk.qtoff[cg / nchq][tap] : ky * hk.dil * hk.RP + kx * hk.dil * HPITCH;
 #pragma unroll
         for (int c = 0; c < NC16; ++c) {
             h8 ah[TM], al[TM];
@@ -225,15 +243,17 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
 
     // ---- prologue: halo of chunk 0 and the first weight fragments
     halo_issue(0);
-    b_load(bfA, 0);
+    b_load(bfA, 0, 0);
     halo_commit();
     __syncthreads();
-    int cg = 0, tap = 0;
-    auto one_step = [&](const BFrag& use, BFrag& fill, int step) {
+    int cg = 0, tap = 0;                                           // the (chunk, tap) step being computed
+    int cgn = 0, tapn = 0;                                         // ... and the one whose weights are being fetched
+    auto one_step = [&](const BFrag& use, BFrag& fill) {
         if (tap == 0 && cg + 1 < nch) halo_issue(cg + 1);          // in flight during all taps of this chunk
-        if (step + 1 < total) b_load(fill, step + 1);
-        compute(tap, use);
-        if (++tap == ntaps) {
+        if (++tapn == taps_of(cgn)) { tapn = 0; ++cgn; }
+        if (cgn < nch) b_load(fill, cgn, tapn);
+        compute(cg, tap, use);
+        if (++tap == taps_of(cg)) {
             tap = 0;
             if (++cg < nch) {
                 __syncthreads();                                   // every wave is done with the old halo
@@ -242,12 +262,12 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             }
         }
     };
-    int step = 0;
-    for (; step + 1 < total; step += 2) {
-        one_step(bfA, bfB, step);
-        one_step(bfB, bfA, step + 1);
+    for (;;) {
+        one_step(bfA, bfB);
+        if (cg >= nch) break;
+        one_step(bfB, bfA);
+        if (cg >= nch) break;
     }
-    if (step < total) one_step(bfA, bfB, step);
 
     // ---------------------------------------------------------------- epilogue
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);

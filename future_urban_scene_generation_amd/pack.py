@@ -59,8 +59,20 @@ class ConvPlan:
             wsplit = split_f16x3(self.wpack)
             self.dev["wpack_h"] = wsplit.to(device).contiguous()
             frag = frag_f16x3(wsplit, self) if self.nphase == 1 else None
+            if frag is not None and self.s2d_ok():
+                frag = frag[s2d_tap_order(self.kh)].contiguous()       # slabs in (parity quadrant, local tap) order
             self.dev["wfrag"] = None if frag is None else frag.to(device).contiguous()
         return self
+
+    def s2d_ok(self) -> bool:
+        """Stride-2 k3/k4 pad-1 layer whose halo-kernel weights are stored in parity-quadrant order
+        (fusg_conv_desc.wfrag_order = 1, see s2d_tap_order)."""
+        import os
+        if os.environ.get("FUSG_NO_S2D"):
+            return False
+        return (self.nphase == 1 and self.stride == 2 and self.kh == self.kw and self.kh in (3, 4) and self.pad == 1
+                and self.dil == 1 and self.upsample == 0 and self.pad_w < 0 and self.c1k == 0 and self.c0k % 32 == 0
+                and self.c0k > 0)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         """q-space output grid for an input of h x w."""
@@ -95,6 +107,21 @@ def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]
     w = w.view(2, nt32, 32, taps, nch, 2, 2, 8)                 # hl, nt, r, tap, chunk, c16, h, j
     w = w.permute(3, 4, 1, 5, 0, 6, 2, 7)                       # tap, chunk, nt, c16, hl, h, r, j
     return w.reshape(taps, nch, nt32, 2, 2, 64, 8).contiguous()
+
+
+def s2d_quadrant_taps(k: int):
+    """A stride-2, pad-1 convolution reads input row 2Y - 1 + ky: parity i = (ky - 1) mod 2 of the rows, sub-row
+    Y + (ky - 1) // 2.  So it is, per parity quadrant (i, j) of the input (x[2Y+i, 2X+j]), a small STRIDE-1
+    convolution of that quarter-size sub-image.  Returns, for q = 2*i + j, the list of (ky, kx, dY, dX)."""
+    per_axis = {0: [], 1: []}
+    for kk in range(k):
+        per_axis[(kk - 1) % 2].append((kk, (kk - 1) // 2))
+    return [[(ky, kx, dy, dx) for ky, dy in per_axis[q >> 1] for kx, dx in per_axis[q & 1]] for q in range(4)]
+
+
+def s2d_tap_order(k: int) -> List[int]:
+    """Order of the k*k taps (row-major index ky*k + kx) in the parity-quadrant weight layout."""
+    return [ky * k + kx for quad in s2d_quadrant_taps(k) for ky, kx, _, _ in quad]
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):

@@ -141,7 +141,11 @@ typedef struct fusg_conv_desc {
      * is used: taps must then be the dense kh x kw grid in (ky, kx) order with
      * dy = ky*dil - pad_h, dx = kx*dil - pad_w, which is what pack.py emits. */
     int32_t kh, kw, dil, pad_h, pad_w;
-    int32_t _pad2;
+    int32_t wfrag_order;         /* 0: wfrag slabs in tap order.  1 (stride 2, k3/k4, pad 1, dil 1, one source with
+                                    channels % 32 == 0, even H and W): slabs grouped by the parity quadrant of the input
+                                    they read (pack.py: s2d_tap_order) - the launch then runs as four stride-1
+                                    convolutions of the quarter-size parity sub-images (halo kernel, 32-channel
+                                    chunks, unit-stride LDS reads) instead of the strided form              */
     /* Halo kernel only: the (hi, lo) fp16 weights again, in MFMA-fragment order
      * [tap][chunk32][cout_pad/32][k-half][hi|lo][64 lanes][8 halves] (pack.py: frag_f16x3), so that a
      * B operand is one contiguous 1 KiB wave load.  NULL disables the halo kernel. */
@@ -234,6 +238,10 @@ int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_ten
 
 int         fusg_version(void);
 const char* fusg_last_error(void);
+/* Kernel family of this thread's last fusg_conv2d launch (tests assert that the intended path ran):
+ * 0 generic fp32, 1 generic split-fp16, 2 halo, 3 halo in parity-quadrant form (stride 2); -1 none yet. */
+enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3 };
+int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their
  * struct mirrors. */

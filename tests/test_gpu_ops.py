@@ -52,6 +52,11 @@ CONVS = [  # B, cin, cout, k, stride, pad, dil, pad_mode, H, W
     (2, 64, 3, 7, 1, 3, 1, 1, 16, 16),       # cout 3 head
     (1, 256, 12, 1, 1, 0, 1, 0, 64, 64),     # score conv
     (2, 128, 128, 3, 1, 1, 1, 0, 64, 64),    # big enough for the 128x128 tile
+    (2, 64, 128, 4, 2, 1, 1, 1, 32, 64),     # stride 2 in parity-quadrant form (halo kernel): ICN down, reflect
+    (2, 64, 128, 4, 2, 1, 1, 0, 32, 64),     # EdgeConnect down, zero
+    (2, 32, 64, 3, 2, 1, 1, 0, 32, 64),      # VUnet DownSample
+    (1, 128, 128, 3, 2, 1, 1, 0, 16, 32),
+    (1, 64, 64, 3, 2, 1, 1, 0, 15, 31),      # odd sizes: same weights, generic gather
 ]
 
 
@@ -151,6 +156,25 @@ def test_conv_up2_phases(B, cin, cout, H, W, precision):
     got = ops.conv_up2(exact, phases, xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)
     assert tuple(got.shape) == tuple(ref.shape)
     _close(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout,k,pm,H,W", [(64, 128, 4, 1, 32, 64), (64, 128, 4, 0, 32, 64), (32, 64, 3, 0, 32, 64),
+                                                (128, 128, 3, 1, 16, 32)])
+def test_conv_stride2_quadrant_form(cin, cout, k, pm, H, W, precision):
+    """Stride-2 k3/k4 layers on the halo kernel in parity-quadrant form (and that this IS the path that runs)."""
+    x = _rand(2, cin, H, W, seed=1)
+    w = _rand(cout, cin, k, k, seed=2, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=3)
+    plan = pack.pack_conv(w, b, stride=2, pad=1, pad_mode=pm)
+    assert plan.s2d_ok()
+    xin = F.pad(x, (1,) * 4, mode="reflect") if pm else F.pad(x, (1,) * 4)
+    ref = F.conv2d(xin, w, b, stride=2)
+    got = ops.conv(plan, _nhwc(x), ksplit=1, pre_op=L.PRE_NONE)
+    assert ops.last_conv_kernel() == (3 if precision == "f16x3" else 0)
+    _close(got, ref)
+    # ELU pre-op + residual through the same path (VUnet DownSample sees ELU'd inputs elsewhere; covers the pre-op kinds)
+    got = ops.conv(plan, _nhwc(x), ksplit=1, pre_op=L.PRE_ELU)
+    _close(got, F.conv2d(F.pad(F.elu(x), (1,) * 4, mode="reflect") if pm else F.pad(F.elu(x), (1,) * 4), w, b, stride=2))
 
 
 def test_conv_tile_list_and_replicate_pad(precision):

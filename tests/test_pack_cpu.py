@@ -80,6 +80,27 @@ def test_up2_phase_weights_identity():
     assert len(plans) == 4 and all(q.kh == 3 and q.pad == 1 and q.pad_mode == 2 and q.upsample == 0 for q in plans)
 
 
+@pytest.mark.parametrize("k,pad_mode", [(4, "reflect"), (4, "zero"), (3, "zero"), (3, "reflect")])
+def test_s2d_quadrant_form_of_stride2_conv(k, pad_mode):
+    """A stride-2 pad-1 conv == the sum over the four parity sub-images x[2Y+i, 2X+j] of small stride-1 convs with
+    the taps pack.s2d_quadrant_taps assigns to them; reflection of the full image becomes a clamp of the sub-image."""
+    x = _rand(2, 5, 12, 16, seed=1)
+    w = _rand(7, 5, k, k, seed=2) * 0.2
+    xin = F.pad(x, (1,) * 4, mode="reflect") if pad_mode == "reflect" else F.pad(x, (1,) * 4)
+    ref = F.conv2d(xin, w, stride=2)
+    Ho, Wo = ref.shape[2:]
+    got = torch.zeros_like(ref)
+    quads = pack.s2d_quadrant_taps(k)
+    assert sorted(pack.s2d_tap_order(k)) == list(range(k * k)) and sum(len(q) for q in quads) == k * k
+    for q, taps in enumerate(quads):
+        sub = x[:, :, (q >> 1)::2, (q & 1)::2]                        # [B, C, H/2, W/2]
+        subp = F.pad(sub, (1,) * 4, mode="replicate") if pad_mode == "reflect" else F.pad(sub, (1,) * 4)
+        for ky, kx, dy, dx in taps:
+            win = subp[:, :, 1 + dy:1 + dy + Ho, 1 + dx:1 + dx + Wo]
+            got += torch.einsum("bchw,oc->bohw", win, w[:, :, ky, kx])
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
 def test_affine_relu_prologue_keeps_padding_zero():
     x = _rand(2, 8, 6, 6, seed=1)
     w = _rand(4, 8, 3, 3, seed=2)

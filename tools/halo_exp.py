@@ -82,6 +82,25 @@ def burst(fn, n=10):
 
 def main():
     g = torch.Generator().manual_seed(0)
+    s2 = [  # name, B, cin, cout, k, pad_mode, H, pre_op
+        ("s2 vu 128->128 3x3 @256 elu", 32, 128, 128, 3, 0, 256, L.PRE_ELU),
+        ("s2 icn 64->128 4x4 @256 affine", 32, 64, 128, 4, 1, 256, L.PRE_AFFINE_RELU),
+        ("s2 icn 128->256 4x4 @128 affine", 32, 128, 256, 4, 1, 128, L.PRE_AFFINE_RELU),
+    ]
+    args0 = [a for a in sys.argv[1:] if not a.startswith("--")]
+    timer0 = burst if "--burst" in sys.argv else sustained
+    for name, B, cin, cout, k, pm, H, pre_op in s2:
+        if args0 and args0[0] not in name:
+            continue
+        w = torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5
+        plan = pack.pack_conv(w, None, stride=2, pad=1, pad_mode=pm)
+        x = ops.as_nhwc(torch.randn(B, cin, H, H, generator=g).to(dev))
+        pre = None
+        if pre_op == L.PRE_AFFINE_RELU:
+            pre = (torch.rand(cin, generator=g).to(dev) + 0.5, torch.randn(cin, generator=g).to(dev) * 0.1)
+        fl = 2.0 * B * (H // 2) ** 2 * cout * cin * k * k
+        ms, mhz, wat = timer0(lambda: ops.conv(plan, x, pre_op=pre_op, pre=pre, precision="f16x3"))
+        print(f"{'kernel ' + str(ops.last_conv_kernel()):22s} {name:30s} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF {mhz:5.0f} MHz {wat:5.0f} W {ms * wat / 1e3:.3f} J", flush=True)
     cases = [  # name, B, cin, cout, k, pad, H, pre_op, upsample, dil
         ("icn 256->256 3x3 @64 affine", 32, 256, 256, 3, 1, 64, L.PRE_AFFINE_RELU, 0, 1),
         ("vu 128->128 3x3 @256 elu", 32, 128, 128, 3, 1, 256, L.PRE_ELU, 0, 1),
