@@ -135,6 +135,15 @@ class VehiclePipeline:
         vehicle_seeds: one VUnet noise seed per sample (e.g. base + global vehicle index) - makes the result of
         a vehicle independent of how the vehicles are sharded over ranks; None = the reference's global RNG."""
         from . import ops
+        B, R = batch["hg_x"].shape[0], batch["hg_x"].shape[-1]
+        if B == 0:                                                # a rank whose shard is empty (fewer vehicles than ranks)
+            dev = self.device
+            out = {"kp_idx": torch.empty((0, 12), dtype=torch.int32, device=dev),
+                   "icn_u8": torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev),
+                   "vunet_u8": torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)}
+            if self.inpaint:
+                out["inpaint_u8"] = torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)
+            return out
         self.vunet.set_vehicle_seeds(vehicle_seeds)
 
         def hg():

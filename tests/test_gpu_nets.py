@@ -260,6 +260,8 @@ def test_sharded_run_equals_unsharded(precision):
         assert np.array_equal(part["kp_idx"].cpu().numpy(), full["kp_idx"][lo:hi])
         for k in ("icn_u8", "vunet_u8"):                                  # tile choices depend on the batch size
             assert np.abs(part[k].cpu().numpy().astype(int) - full[k][lo:hi].astype(int)).max() <= 1, k
+    empty = pipe.run({k: v[:0] for k, v in batch.items()})               # a rank with no vehicles
+    assert tuple(empty["kp_idx"].shape) == (0, 12) and tuple(empty["vunet_u8"].shape) == (0, R, R, 3)
     # and the default (reference) mode is untouched by a previous seeded run
     torch.manual_seed(3)
     a = pipe.run(batch)["vunet_u8"].cpu().numpy()
