@@ -124,6 +124,18 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     const int nphase = d->nphase > 0 ? d->nphase : 1;
     FUSG_CHECK(nphase == 1 || nphase == 4, "conv2d: nphase %d", nphase);
     FUSG_CHECK(d->qh > 0 && d->qw > 0, "conv2d: empty output grid");
+    FUSG_CHECK(d->q_oy >= 0 && d->q_ox >= 0 && (d->store_mode == FUSG_STORE_NORMAL || (d->q_oy | d->q_ox) == 0) &&
+               !(d->stats_out && (d->q_oy | d->q_ox)), "conv2d: q-space origin (%d, %d)", d->q_oy, d->q_ox);
+    if (nphase == 1 && d->kh > 0 && d->kw > 0) {
+        // the q window must stay inside the convolution's own output range: every tap then lands within one
+        // padding width of the (virtual) input, which is all the gathers' single reflection / clamp handles
+        const long Hv = x0.h << d->upsample, Wv = x0.w << d->upsample;
+        FUSG_CHECK(d->dil >= 1 && d->pad_h >= 0 && d->pad_w >= 0 &&
+                   (long)(d->q_oy + d->qh - 1) * d->stride + (long)(d->kh - 1) * d->dil - d->pad_h <= Hv - 1 + d->pad_h &&
+                   (long)(d->q_ox + d->qw - 1) * d->stride + (long)(d->kw - 1) * d->dil - d->pad_w <= Wv - 1 + d->pad_w &&
+                   (d->pad_mode == FUSG_PAD_ZERO || (d->pad_h <= Hv - 1 && d->pad_w <= Wv - 1)),
+                   "conv2d: q window [%d+%d, %d+%d] reaches outside the padded input", d->q_oy, d->qh, d->q_ox, d->qw);
+    }
     const long Ml = (long)x0.n * d->qh * d->qw;
     FUSG_CHECK(Ml > 0 && Ml < (1L << 31), "conv2d: M out of range");
     FUSG_CHECK(x0.n * x0.h * x0.w * x0.sw < (1L << 40), "conv2d: src too large");
@@ -142,8 +154,9 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         oh = 0; ow = 0;
         for (int ph = 0; ph < nphase; ++ph) {
             FUSG_CHECK(d->out_oy[ph] >= 0 && d->out_ox[ph] >= 0, "conv2d: negative phase offset");
-            oh = oh > (long)(d->qh - 1) * d->out_sy + d->out_oy[ph] + 1 ? oh : (long)(d->qh - 1) * d->out_sy + d->out_oy[ph] + 1;
-            ow = ow > (long)(d->qw - 1) * d->out_sx + d->out_ox[ph] + 1 ? ow : (long)(d->qw - 1) * d->out_sx + d->out_ox[ph] + 1;
+            const long eh = (long)(d->q_oy + d->qh - 1) * d->out_sy + d->out_oy[ph] + 1, ew = (long)(d->q_ox + d->qw - 1) * d->out_sx + d->out_ox[ph] + 1;
+            oh = oh > eh ? oh : eh;
+            ow = ow > ew ? ow : ew;
         }
         oc = d->cout;
     }
@@ -172,6 +185,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     if (d->res0.data) { k.res0 = (const float*)d->res0.data; k.r0n = d->res0.sn; k.r0c = d->res0.sc; k.r0h = d->res0.sh; k.r0w = d->res0.sw; }
     if (d->res1.data) { k.res1 = (const float*)d->res1.data; k.r1n = d->res1.sn; k.r1c = d->res1.sc; k.r1h = d->res1.sh; k.r1w = d->res1.sw; }
     k.ws = d->workspace;
+    k.qy0 = d->q_oy; k.qx0 = d->q_ox;
     k.zeros = zero_line();
     if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
     k.wpack_h = (const _Float16*)d->wpack_h;
@@ -224,7 +238,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
-                         getenv("FUSG_NO_HALO") == nullptr &&
+                         getenv("FUSG_NO_HALO") == nullptr && (d->q_oy | d->q_ox) == 0 &&
                          !(d->wfrag_order == 1 && (x0.h % 2 != 0 || x0.w % 2 != 0 || d->stride != 2));   // odd sizes: generic gather
     if (halo_ok) {
         HaloK h;

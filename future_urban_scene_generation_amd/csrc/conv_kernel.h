@@ -51,6 +51,7 @@ struct ConvK {
     int vec_epi;             // destination / residuals allow 16-byte channel-contiguous epilogue accesses
     float* stats;            // optional fused norm statistics: [B][stats_slots][Cout][2] = (mean, M2) per 32-pixel slot
     int stats_slots;         // slots per image = qh*qw/32
+    int qy0, qx0;            // origin of the computed Ho x Wo window in q-space (generic kernels; 0 for the halo kernel)
     const float* zeros;      // 256 B of zeros in device memory: where the gather of a zero-padded pixel reads.  It
                              // comes in through the kernel arguments so that the selected pointer stays a GLOBAL
                              // one (a select against the address of a __device__ variable degrades the load to
@@ -80,8 +81,8 @@ __device__ __forceinline__ bool pix_offsets(const ConvK& p, int phase, int m, Pi
     const int hw = p.Ho * p.Wo;
     const int b = m / hw;
     const int rem = m - b * hw;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
+    const int oy = rem / p.Wo + p.qy0;
+    const int ox = rem - (oy - p.qy0) * p.Wo + p.qx0;
     long Y, X, cq = 0;
     if (p.store_mode == FUSG_STORE_D2S) { Y = 2 * oy; X = 2 * ox; }
     else if (p.store_mode == FUSG_STORE_S2D) { Y = oy >> 1; X = ox >> 1; cq = (long)(((oy & 1) << 1) | (ox & 1)) * p.Cout; }
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
             const int b = m / hw;
             const int rem = m - b * hw;
             const int oy = rem / p.Wo;
-            rb[i] = b; riy[i] = oy * p.stride; rix[i] = (rem - oy * p.Wo) * p.stride;
+            rb[i] = b; riy[i] = (oy + p.qy0) * p.stride; rix[i] = (rem - oy * p.Wo + p.qx0) * p.stride;
         } else { rb[i] = -1; riy[i] = 0; rix[i] = 0; }
         rowoff[i] = rb[i] < 0 ? 0 : ((long)(rb[i] * p.H + riy[i]) * p.W + rix[i]);
     }

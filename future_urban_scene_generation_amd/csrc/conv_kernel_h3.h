@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             const int b = m / hw;
             const int rem = m - b * hw;
             const int oy = rem / p.Wo;
-            rb[i] = b; riy[i] = oy * p.stride; rix[i] = (rem - oy * p.Wo) * p.stride;
+            rb[i] = b; riy[i] = (oy + p.qy0) * p.stride; rix[i] = (rem - oy * p.Wo + p.qx0) * p.stride;
         } else { rb[i] = -1; riy[i] = 0; rix[i] = 0; }
         rowoff[i] = rb[i] < 0 ? 0 : ((long)(rb[i] * p.H + riy[i]) * p.W + rix[i]);
     }

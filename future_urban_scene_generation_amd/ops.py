@@ -130,12 +130,14 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
          pre_op: int = L.PRE_NONE, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_bstride: int = 0,
          act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
          ksplit: int = 0, precision: Optional[str] = None, want_stats: bool = False,
-         out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), tiles: Optional[torch.Tensor] = None):
+         out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), tiles: Optional[torch.Tensor] = None,
+         q_window: Optional[Tuple[int, int, int, int]] = None):
     """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
     unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result).
     out_stride / out_off: write output pixel (qy, qx) at (qy*out_stride + out_off[0], qx*out_stride + out_off[1])
     of `out` (phase launches).  tiles: int32 device tensor of 8x16-pixel patch indices - compute only those
-    (halo-kernel launches only)."""
+    (halo-kernel launches only).  q_window = (oy, ox, h, w): compute only that window of the output grid (into the
+    same positions of `out`, which must be given)."""
     plan.to(x0.device)
     b, c0, h, w = x0.shape
     assert c0 == plan.c_split[0], (x0.shape, plan.c_split)
@@ -145,6 +147,9 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     else:
         assert x1 is None
     qh, qw = plan.out_hw(h, w)
+    if q_window is not None:
+        assert out is not None and plan.nphase == 1 and store == L.STORE_NORMAL and not want_stats
+        assert 0 <= q_window[0] and q_window[0] + q_window[2] <= qh and 0 <= q_window[1] and q_window[1] + q_window[3] <= qw
     if plan.nphase == 4:
         oc, oh, ow = plan.cout, 2 * qh, 2 * qw
     elif store == L.STORE_D2S:
@@ -173,6 +178,8 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     d.k_pad, d.c0k, d.cout, d.cout_pad = plan.k_pad, plan.c0k, plan.cout, plan.cout_pad
     d.stride, d.upsample, d.pad_mode = plan.stride, plan.upsample, plan.pad_mode
     d.pre_op, d.act, d.store_mode = int(pre_op), int(act), int(store)
+    if q_window is not None:
+        d.q_oy, d.q_ox, qh, qw = (int(v) for v in q_window)
     d.qh, d.qw, d.nphase = qh, qw, plan.nphase
     if plan.nphase == 4:
         d.out_sy = d.out_sx = 2
@@ -248,7 +255,8 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     """nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv.  `exact` = the 25-tap plan with the upsample fused into its
     gather (pack_conv(..., upsample=1)); `phases` = pack_conv_up2_phases of the same filter.  When the shapes qualify,
     four 3x3 phase launches on the low-res input (9 MACs per output instead of 25) write the interleaved output and
-    the 25-tap form then recomputes the border patches, the only place the two differ (pack.up2_phase_weights)."""
+    the 25-tap form then recomputes the outermost ring of pixels, the only place the two differ
+    (pack.up2_phase_weights)."""
     if phases is None or not up2_phases_ok(x, precision):
         return conv(exact, x, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)
     b, c, h, w = x.shape
@@ -256,8 +264,9 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     for ph, plan in enumerate(phases):                              # ksplit=1: split-K launches do not use the halo kernel
         conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
              precision=precision, ksplit=1)
-    conv(exact, x, out=out, tiles=border_tiles(2 * h, 2 * w, x.device), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
-         precision=precision, ksplit=1)
+    # the outermost ring of output pixels, with the 25-tap form: four one-pixel-wide windows of the full convolution
+    for win in ((0, 0, 1, 2 * w), (2 * h - 1, 0, 1, 2 * w), (0, 0, 2 * h, 1), (0, 2 * w - 1, 2 * h, 1)):
+        conv(exact, x, out=out, q_window=win, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)
     return out
 
 

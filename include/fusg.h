@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 101
+#define FUSG_VERSION 102
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -161,6 +161,9 @@ typedef struct fusg_conv_desc {
      * patches of every image - indices into the row-major (qh/8) x (qw/16) patch grid, device memory. */
     const int32_t* tile_list;
     int32_t        tile_count;
+    /* Origin of the computed qh x qw window in q-space (default 0, 0): output pixel (qy, qx) of the launch is
+     * pixel (q_oy + qy, q_ox + qx) of the full convolution - lets a launch compute one edge row or column. */
+    int32_t        q_oy, q_ox;
     int32_t        _pad3;
 } fusg_conv_desc;
 

@@ -177,6 +177,32 @@ def test_conv_stride2_quadrant_form(cin, cout, k, pm, H, W, precision):
     _close(got, F.conv2d(F.pad(F.elu(x), (1,) * 4, mode="reflect") if pm else F.pad(F.elu(x), (1,) * 4), w, b, stride=2))
 
 
+def test_conv_q_window():
+    """q_window computes one window of the output grid (edge rows / columns of a fused-upsample reflect conv), leaves
+    the rest of `out` alone, and the library refuses a window that leaves the convolution's output range."""
+    x = _rand(2, 32, 9, 11, seed=1)
+    w = _rand(24, 32, 5, 5, seed=2, scale=0.05)
+    b = _rand(24, seed=3)
+    plan = pack.pack_conv(w, b, pad=2, pad_mode=1, upsample=1)
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (2,) * 4, mode="reflect"), w, b)
+    H, W = ref.shape[2:]
+    out = ops.nhwc_empty(2, 24, H, W, dev())
+    out.fill_(-3.0)
+    want = torch.full_like(ref, -3.0)
+    for oy, ox, h, ww in ((0, 0, 1, W), (H - 1, 0, 1, W), (0, 0, H, 1), (0, W - 1, H, 1), (3, 4, 5, 6)):
+        ops.conv(plan, _nhwc(x), out=out, q_window=(oy, ox, h, ww))
+        want[:, :, oy:oy + h, ox:ox + ww] = ref[:, :, oy:oy + h, ox:ox + ww]
+    _close(out, want)
+    d_ok = False
+    try:
+        ops.conv(plan, _nhwc(x), out=out, q_window=(0, 0, H, W))
+        d_ok = True
+    finally:
+        assert d_ok
+    with pytest.raises(AssertionError):
+        ops.conv(plan, _nhwc(x), out=out, q_window=(0, 0, H + 1, W))
+
+
 def test_conv_tile_list_and_replicate_pad(precision):
     """tile_list computes only the listed 8x16 patches; PAD_REPLICATE = edge clamp (halo-kernel launches only)."""
     if precision != "f16x3":
