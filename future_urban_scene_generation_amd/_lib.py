@@ -101,6 +101,11 @@ def lib():
             raise FusgUnavailable(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libfusg.so is linked against the
+        # system one (same SONAME).  Whichever is mapped first serves both, so torch goes first - loaded the other
+        # way round, torch would run on a runtime it was not built for and the library's launches fail with
+        # "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         try:
             h = C.CDLL(LIB_PATH)
         except OSError as e:                         # pragma: no cover
