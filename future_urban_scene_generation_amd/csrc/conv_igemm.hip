@@ -233,7 +233,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         case FUSG_PRE_AFFINE: pk = PK_AFFINE; break;
         default: break;
     }
-    const bool gen = d->pad_mode == FUSG_PAD_REFLECT || d->upsample != 0;
+    const bool gen = d->pad_mode != FUSG_PAD_ZERO || d->upsample != 0;
     const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->upsample + d->stride <= 2 && d->ksplit <= 1 &&
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
@@ -297,8 +297,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
             return FUSG_OK;
         }
     }
-    if (d->tile_list || d->pad_mode == FUSG_PAD_REPLICATE) {
-        set_error("conv2d: tile_list / PAD_REPLICATE need a launch that qualifies for the halo kernel");
+    if (d->tile_list) {
+        set_error("conv2d: tile_list needs a launch that qualifies for the halo kernel");
         prof_end(0, s);
         return FUSG_ERR_UNSUPPORTED;
     }

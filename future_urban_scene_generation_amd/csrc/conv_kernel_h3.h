@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                 if (p.pad_mode == FUSG_PAD_REFLECT) {
                     iy = iy < 0 ? -iy : (iy >= p.Hv ? 2 * p.Hv - 2 - iy : iy);
                     ix = ix < 0 ? -ix : (ix >= p.Wv ? 2 * p.Wv - 2 - ix : ix);
+                } else if (p.pad_mode == FUSG_PAD_REPLICATE) {
+                    iy = min(max(iy, 0), p.Hv - 1);
+                    ix = min(max(ix, 0), p.Wv - 1);
                 } else {
                     ok = ok && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
                 }

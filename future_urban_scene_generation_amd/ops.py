@@ -244,10 +244,10 @@ def border_tiles(h: int, w: int, device) -> torch.Tensor:
 
 
 def up2_phases_ok(x: torch.Tensor, precision: Optional[str] = None) -> bool:
-    """Does `conv_up2` take the 4-phase route for this input?  (All five launches must qualify for the halo kernel.)"""
+    """Does `conv_up2` take the 4-phase route for this input?  (Any shape the reflect padding itself allows; the
+    launches use the halo kernel where they qualify and the generic gather elsewhere.)"""
     b, c, h, w = x.shape
-    return ((precision or PRECISION) == "f16x3" and c % 32 == 0 and h % 8 == 0 and w % 16 == 0 and h >= 8 and w >= 16
-            and _os.environ.get("FUSG_NO_HALO") is None and _os.environ.get("FUSG_NO_UP2_PHASES") is None)
+    return h >= 2 and w >= 2 and _os.environ.get("FUSG_NO_UP2_PHASES") is None
 
 
 def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
@@ -261,9 +261,12 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
         return conv(exact, x, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)
     b, c, h, w = x.shape
     out = nhwc_empty(b, exact.cout, 2 * h, 2 * w, x.device)
-    for ph, plan in enumerate(phases):                              # ksplit=1: split-K launches do not use the halo kernel
+    # split-K launches do not use the halo kernel: keep K whole where the phase launches qualify for it
+    halo = ((precision or PRECISION) == "f16x3" and c % 32 == 0 and h % 8 == 0 and w % 16 == 0
+            and _os.environ.get("FUSG_NO_HALO") is None)
+    for ph, plan in enumerate(phases):
         conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
-             precision=precision, ksplit=1)
+             precision=precision, ksplit=1 if halo else 0)
     # the outermost ring of output pixels, with the 25-tap form: four one-pixel-wide windows of the full convolution
     for win in ((0, 0, 1, 2 * w), (2 * h - 1, 0, 1, 2 * w), (0, 0, 2 * h, 1), (0, 2 * w - 1, 2 * h, 1)):
         conv(exact, x, out=out, q_window=win, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)

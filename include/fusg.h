@@ -52,8 +52,8 @@ typedef struct fusg_tensor {
 
 typedef enum fusg_pad_mode {
     FUSG_PAD_ZERO = 0, FUSG_PAD_REFLECT = 1,
-    FUSG_PAD_REPLICATE = 2     /* clamp to the edge; halo-kernel launches only (the phase form of
-                                  nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv, pack.py) */
+    FUSG_PAD_REPLICATE = 2     /* clamp to the edge (the phase form of nn.Upsample(2) -> ReflectionPad2d(2) ->
+                                  5x5 conv, pack.py: up2_phase_weights) */
 } fusg_pad_mode;
 
 /* op applied to every in-bounds source element while the im2col tile is staged (padding stays 0) */

@@ -152,7 +152,7 @@ def test_conv_up2_phases(B, cin, cout, H, W, precision):
     ref = F.conv2d(F.pad(F.interpolate(xin, scale_factor=2, mode="nearest"), (2,) * 4, mode="reflect"), w, b)
     pre = (sc.to(dev()).contiguous(), sh.to(dev()).contiguous())
     xd = _nhwc(x)
-    assert ops.up2_phases_ok(xd) == (precision == "f16x3" and H % 8 == 0 and W % 16 == 0)
+    assert ops.up2_phases_ok(xd)
     got = ops.conv_up2(exact, phases, xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)
     assert tuple(got.shape) == tuple(ref.shape)
     _close(got, ref)
@@ -204,18 +204,17 @@ def test_conv_q_window():
 
 
 def test_conv_tile_list_and_replicate_pad(precision):
-    """tile_list computes only the listed 8x16 patches; PAD_REPLICATE = edge clamp (halo-kernel launches only)."""
-    if precision != "f16x3":
-        x = _nhwc(_rand(1, 32, 16, 32, seed=1))
-        plan = pack.pack_conv(_rand(32, 32, 3, 3, seed=2) * 0.05, None, pad=1, pad_mode=L.PAD_REPLICATE)
-        with pytest.raises(RuntimeError):
-            ops.conv(plan, x)                                      # no halo kernel on the exact-fp32 path
-        return
+    """PAD_REPLICATE = edge clamp on every conv path; tile_list computes only the listed 8x16 patches (halo kernel)."""
     x = _rand(2, 32, 24, 48, seed=1)
     w = _rand(32, 32, 3, 3, seed=2, scale=0.05)
     ref = F.conv2d(F.pad(x, (1,) * 4, mode="replicate"), w)
     plan = pack.pack_conv(w, None, pad=1, pad_mode=L.PAD_REPLICATE)
-    _close(ops.conv(plan, _nhwc(x), ksplit=1), ref)                # (split-K launches do not use the halo kernel)
+    _close(ops.conv(plan, _nhwc(x), ksplit=1), ref)                # halo kernel on the split-fp16 path
+    _close(ops.conv(plan, _nhwc(x)), ref)                          # split-K -> generic gather
+    if precision != "f16x3":
+        with pytest.raises(RuntimeError):
+            ops.conv(plan, _nhwc(x), tiles=ops.border_tiles(24, 48, dev()))       # tile lists are a halo-kernel feature
+        return
     tiles = ops.border_tiles(24, 48, dev())                        # 3 x 3 patch grid: all but the centre patch
     assert sorted(tiles.cpu().tolist()) == [0, 1, 2, 3, 5, 6, 7, 8]
     out = ops.nhwc_empty(2, 32, 24, 48, dev())
