@@ -250,6 +250,11 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.wfrag = (const _Float16*)d->wfrag;
         h.nt32 = d->cout_pad / 32;
         int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+        {   // small grids: narrower column tiles until the launch has enough workgroups to fill the chip
+            static const long min_wg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
+            const long mt = (long)x0.n * (d->tile_list ? d->tile_count : (d->qh / 8) * (d->qw / 16));
+            while (bn > 32 && mt * (d->cout_pad / bn) < min_wg) bn /= 2;
+        }
         if (const char* ev = getenv("FUSG_HALO_BN")) { const int v = atoi(ev); if ((v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v; }
         h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
