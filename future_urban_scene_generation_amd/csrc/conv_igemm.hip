@@ -130,10 +130,12 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         // the q window must stay inside the convolution's own output range: every tap then lands within one
         // padding width of the (virtual) input, which is all the gathers' single reflection / clamp handles
         const long Hv = x0.h << d->upsample, Wv = x0.w << d->upsample;
+        // (zero padding bounds-checks every tap, so any window is safe there)
         FUSG_CHECK(d->dil >= 1 && d->pad_h >= 0 && d->pad_w >= 0 &&
-                   (long)(d->q_oy + d->qh - 1) * d->stride + (long)(d->kh - 1) * d->dil - d->pad_h <= Hv - 1 + d->pad_h &&
-                   (long)(d->q_ox + d->qw - 1) * d->stride + (long)(d->kw - 1) * d->dil - d->pad_w <= Wv - 1 + d->pad_w &&
-                   (d->pad_mode == FUSG_PAD_ZERO || (d->pad_h <= Hv - 1 && d->pad_w <= Wv - 1)),
+                   (d->pad_mode == FUSG_PAD_ZERO ||
+                    ((long)(d->q_oy + d->qh - 1) * d->stride + (long)(d->kh - 1) * d->dil - d->pad_h <= Hv - 1 + d->pad_h &&
+                     (long)(d->q_ox + d->qw - 1) * d->stride + (long)(d->kw - 1) * d->dil - d->pad_w <= Wv - 1 + d->pad_w &&
+                     d->pad_h <= Hv - 1 && d->pad_w <= Wv - 1)),
                    "conv2d: q window [%d+%d, %d+%d] reaches outside the padded input", d->q_oy, d->qh, d->q_ox, d->qw);
     }
     const long Ml = (long)x0.n * d->qh * d->qw;
@@ -218,6 +220,10 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         }
         k.stats = d->stats_out;
         k.stats_slots = (int)(((long)d->qh * d->qw) / 32);
+        if (d->stats_slots > 0) {
+            if (d->stats_slots < k.stats_slots) { set_error("conv2d: stats_slots %d < %d slots of this launch", d->stats_slots, k.stats_slots); return FUSG_ERR_INVALID; }
+            k.stats_slots = d->stats_slots;
+        }
     }
 
     dim3 grid(k.MT * k.NT, nphase, d->ksplit);

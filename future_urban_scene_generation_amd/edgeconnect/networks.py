@@ -81,6 +81,9 @@ class _Generator(FusedNet):
              "mid": [],
              "up1": pack.pack_conv_transpose_k4s2p1(*self._wb(d[0])).to(device),
              "up2": pack.pack_conv_transpose_k4s2p1(*self._wb(d[3])).to(device),
+             # the same filters as four dense 2x2 plans each: halo-kernel launches with fused IN statistics
+             "up1_ph": [q.to(device) for q in pack.pack_conv_transpose_k4s2p1_phases(*self._wb(d[0]))],
+             "up2_ph": [q.to(device) for q in pack.pack_conv_transpose_k4s2p1_phases(*self._wb(d[3]))],
              "head": pack.pack_conv_rowsplit(*self._wb(d[7]), pad=3, pad_mode=L.PAD_REFLECT).to(device)}
         for blk in self.middle:
             dl = blk.dilation
@@ -100,8 +103,10 @@ class _Generator(FusedNet):
             a, sa = ops.conv_in(pa, y)
             b, sb = ops.conv_in(pb, a, pre_op=AR, pre=sa, pre_bstride=a.shape[1])
             y = ops.affine_act(b, sb[0], sb[1], L.ACT_NONE, res=y)
-        c, st = ops.conv_in(P["up1"], y)                    # transposed convs: statistics fall back to the streaming pass
-        c, st = ops.conv_in(P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
+        def halo_ok(t):                                      # every phase launch qualifies for the halo kernel
+            return ops.PRECISION == "f16x3" and t.shape[1] % 32 == 0 and t.shape[2] % 8 == 0 and t.shape[3] % 16 == 0
+        c, st = ops.conv_in(P["up1_ph"] if halo_ok(y) else P["up1"], y)
+        c, st = ops.conv_in(P["up2_ph"] if halo_ok(c) else P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         return ops.conv_rowsplit(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -131,13 +131,16 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
          act: int = L.ACT_NONE, store: int = L.STORE_NORMAL, nchw_out: bool = False, tile: int = L.TILE_AUTO,
          ksplit: int = 0, precision: Optional[str] = None, want_stats: bool = False,
          out_stride: int = 1, out_off: Tuple[int, int] = (0, 0), tiles: Optional[torch.Tensor] = None,
-         q_window: Optional[Tuple[int, int, int, int]] = None):
+         q_window: Optional[Tuple[int, int, int, int]] = None, q_size: Optional[Tuple[int, int]] = None,
+         stats_into: Optional[Tuple[torch.Tensor, int]] = None):
     """One fused convolution launch (fusg_conv2d).  Returns the output tensor (allocated NHWC-physical
     unless `out` is given or `nchw_out` asks for a standard-contiguous NCHW result).
     out_stride / out_off: write output pixel (qy, qx) at (qy*out_stride + out_off[0], qx*out_stride + out_off[1])
     of `out` (phase launches).  tiles: int32 device tensor of 8x16-pixel patch indices - compute only those
     (halo-kernel launches only).  q_window = (oy, ox, h, w): compute only that window of the output grid (into the
-    same positions of `out`, which must be given)."""
+    same positions of `out`, which must be given).  q_size = (qh, qw): output grid of a launch whose padding is not
+    symmetric (transposed-conv phases; zero padding only).  stats_into = (buffer [B, slots, cout, 2], first_slot): write
+    this launch's fused statistics slots there (the launch must qualify)."""
     plan.to(x0.device)
     b, c0, h, w = x0.shape
     assert c0 == plan.c_split[0], (x0.shape, plan.c_split)
@@ -147,6 +150,9 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     else:
         assert x1 is None
     qh, qw = plan.out_hw(h, w)
+    if q_size is not None:
+        assert out is not None and plan.nphase == 1 and plan.pad_mode == L.PAD_ZERO and q_window is None
+        qh, qw = int(q_size[0]), int(q_size[1])
     if q_window is not None:
         assert out is not None and plan.nphase == 1 and store == L.STORE_NORMAL and not want_stats
         assert 0 <= q_window[0] and q_window[0] + q_window[2] <= qh and 0 <= q_window[1] and q_window[1] + q_window[3] <= qw
@@ -218,6 +224,12 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
                 and out.stride(3) % 4 == 0):
             stats = torch.empty((b, qh * qw // 32, plan.cout, 2), device=x0.device, dtype=torch.float32)
             d.stats_out = stats.data_ptr()
+    if stats_into is not None:
+        buf, first = stats_into
+        assert buf.dtype == torch.float32 and buf.is_contiguous() and buf.shape[0] == b and buf.shape[2] == plan.cout
+        assert (qh * qw) % 32 == 0 and first + qh * qw // 32 <= buf.shape[1]
+        d.stats_out = buf.data_ptr() + first * plan.cout * 2 * 4
+        d.stats_slots = int(buf.shape[1])
     L.check(lib.fusg_conv2d(C.byref(d), stream_ptr()), "conv2d")
     return (out, stats) if want_stats else out
 
@@ -273,6 +285,25 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     return out
 
 
+def conv_transpose_phases(phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
+                          act: int = L.ACT_NONE, want_stats: bool = False, precision: Optional[str] = None):
+    """nn.ConvTranspose2d(k4, s2, p1) as four dense 2x2 stride-1 launches with strided stores
+    (pack.pack_conv_transpose_k4s2p1_phases): each one qualifies for the halo kernel when the input does
+    (split-fp16, channels % 32 == 0, H % 8 == 0, W % 16 == 0).  With want_stats the four launches write disjoint
+    slot ranges of one statistics buffer: returns (out, stats [B, 4*h*w/32, cout, 2] or None)."""
+    b, c, h, w = x.shape
+    cout = phases[0].cout
+    out = nhwc_empty(b, cout, 2 * h, 2 * w, x.device)
+    n = h * w // 32
+    fuse = (want_stats and act == L.ACT_NONE and (h * w) % 32 == 0 and cout % 4 == 0)
+    stats = torch.empty((b, 4 * n, cout, 2), device=x.device, dtype=torch.float32) if fuse else None
+    for ph, plan in enumerate(phases):
+        conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), q_size=(h, w), pre_op=pre_op, pre=pre,
+             pre_bstride=pre_bstride, act=act, precision=precision, ksplit=1,
+             stats_into=(stats, ph * n) if fuse else None)
+    return (out, stats) if want_stats else out
+
+
 def conv_rowsplit(plan: ConvPlan, x0: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
                   act: int = L.ACT_NONE, nchw_out: bool = True) -> torch.Tensor:
     """Small-cout head (pack.pack_conv_rowsplit): kh x 1 implicit GEMM + horizontal gather-sum."""
@@ -326,7 +357,10 @@ def layernorm_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
 def conv_in(plan: ConvPlan, x0: torch.Tensor, eps: float = 1e-5, **kw):
     """conv followed by InstanceNorm2d statistics: returns (raw conv output, (scale, shift)).  The statistics
     come out of the conv epilogue when the launch qualifies, else from the streaming pass."""
-    out, stats = conv(plan, x0, want_stats=True, **kw)
+    if isinstance(plan, (list, tuple)):                               # transposed conv as four phase plans
+        out, stats = conv_transpose_phases(plan, x0, want_stats=True, **kw)
+    else:
+        out, stats = conv(plan, x0, want_stats=True, **kw)
     if stats is None:
         return out, instnorm_stats(out, eps)
     b, nslots, c, _ = stats.shape

@@ -243,6 +243,32 @@ def pack_conv_transpose_k4s2p1(weight: torch.Tensor, bias: Optional[torch.Tensor
                     pad_mode=0, upsample=0, nphase=4, flops_per_pixel=2.0 * cout * cin * 16)
 
 
+def pack_conv_transpose_k4s2p1_phases(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> List[ConvPlan]:
+    """The same four phase convolutions as pack_conv_transpose_k4s2p1, as separate dense 2x2 stride-1 ConvPlans
+    (index 2*py + px) so that each can run on the halo kernel with strided stores (ops.conv_transpose_phases):
+    along an axis, output parity 0 reads input offsets {-1, 0} with ky {3, 1} (a 2-tap filter with padding 1),
+    parity 1 reads {0, +1} with ky {2, 0} (padding 0); taps that fall outside the input contribute nothing."""
+    w = weight.detach().to("cpu", torch.float32)
+    cin, cout, kh, kw = w.shape
+    assert kh == 4 and kw == 4
+    wc = w.permute(1, 0, 2, 3).contiguous()          # [cout, cin, ky, kx]
+    kmap = {0: (3, 1), 1: (2, 0)}
+    plans = []
+    for py in (0, 1):
+        for px in (0, 1):
+            ph, pw = 1 - py, 1 - px
+            taps = [(kmap[py][a], kmap[px][b], a - ph, b - pw) for a in range(2) for b in range(2)]
+            panel, tab, c0k, c1k, k_pad, cout_pad = _pack_panel(wc, taps, (cin,))
+            bb = torch.zeros(cout_pad, dtype=torch.float32)
+            if bias is not None:
+                bb[:cout] = bias.detach().to("cpu", torch.float32)
+            plans.append(ConvPlan(wpack=panel[None].contiguous(), bias=bb, ktab=tab[None].contiguous(), cout=cout,
+                                  cout_pad=cout_pad, k_pad=k_pad, c_split=(cin,), c0k=c0k, c1k=c1k, kh=2, kw=2, stride=1,
+                                  pad=ph, dil=1, pad_mode=0, upsample=0, nphase=1, flops_per_pixel=2.0 * cout * cin * 4,
+                                  pad_w=pw))
+    return plans
+
+
 def pack_conv_rowsplit(weight: torch.Tensor, bias: Optional[torch.Tensor], *, pad: int, pad_mode: int = 0) -> ConvPlan:
     """Small-cout kh x kw convolution as a kh x 1 implicit GEMM with cout*kw (<= 32) output columns:
     t[., co*kw + kx] = sum_{ky, c} in[y + ky - pad, x, c] * w[co, c, ky, kx]; the horizontal taps are

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 102
+#define FUSG_VERSION 103
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -164,7 +164,10 @@ typedef struct fusg_conv_desc {
     /* Origin of the computed qh x qw window in q-space (default 0, 0): output pixel (qy, qx) of the launch is
      * pixel (q_oy + qy, q_ox + qx) of the full convolution - lets a launch compute one edge row or column. */
     int32_t        q_oy, q_ox;
-    int32_t        _pad3;
+    /* Slots per image in stats_out (0 = qh*qw/32): lets several launches that each cover part of an image (the four
+     * phase launches of a transposed convolution) write disjoint slot ranges of one buffer - offset the stats_out
+     * pointer by first_slot*cout*2 floats. */
+    int32_t        stats_slots;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);

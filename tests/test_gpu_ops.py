@@ -235,6 +235,27 @@ def test_conv_transpose():
     _close(ops.conv(plan, _nhwc(x)), F.conv_transpose2d(x, w, b, stride=2, padding=1))
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 32, 16, 32), (32, 64, 8, 16), (32, 16, 10, 12)])
+def test_conv_transpose_phases(cin, cout, H, W, precision):
+    """ConvTranspose2d(k4,s2,p1) as four dense 2x2 launches (halo kernel where the shape qualifies) + the InstanceNorm
+    statistics fused across the four launches."""
+    x = _rand(2, cin, H, W, seed=1)
+    w = _rand(cin, cout, 4, 4, seed=2, scale=0.05)
+    b = _rand(cout, seed=3)
+    ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    phases = pack.pack_conv_transpose_k4s2p1_phases(w, b)
+    out, stats = ops.conv_transpose_phases(phases, _nhwc(x), want_stats=True)
+    _close(out, ref)
+    halo = precision == "f16x3" and H % 8 == 0 and W % 16 == 0
+    assert ops.last_conv_kernel() == (2 if halo else (1 if precision == "f16x3" else 0))
+    out2, (sc, sh) = ops.conv_in(phases, _nhwc(x))
+    _close(out2, ref)
+    mean, var = ref.mean(dim=(2, 3)), ref.var(dim=(2, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    _close(sc, rstd, rtol=2e-4, atol=2e-4)
+    _close(sh, -mean * rstd, rtol=2e-4, atol=5e-4)
+
+
 def test_conv_depth_to_space_store_and_channel_slice():
     import oracle
     x = _rand(2, 16, 5, 6, seed=1)
