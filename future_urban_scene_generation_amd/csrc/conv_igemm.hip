@@ -1,7 +1,7 @@
 // Host side of the fused implicit-GEMM convolution: descriptor validation, tile / split-K
 // heuristics, launch, and the deterministic split-K slab reduction.  Kernel: conv_kernel.h.
 #include <mutex>
-#include "conv_kernel_halo.h"
+#include "conv_kernel_tapunit.h"
 
 namespace fusg {
 
@@ -244,8 +244,48 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
-                         getenv("FUSG_NO_HALO") == nullptr && (d->q_oy | d->q_ox) == 0 &&
+                         getenv("FUSG_NO_HALO") == nullptr && (d->q_oy | d->q_ox) == 0 && d->wfrag_order != 2 &&
                          !(d->wfrag_order == 1 && (x0.h % 2 != 0 || x0.w % 2 != 0 || d->stride != 2));   // odd sizes: generic gather
+    // few-channel k x k layers (the 7x7 stems): tap-unit kernel (conv_kernel_tapunit.h)
+    if (d->wfrag_order == 2) {
+        const int unit = d->c0k % 8 == 0 ? 8 : 4;
+        const int nunits = d->kh * d->kw * (d->c0k / unit);
+        const bool ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->upsample == 0 && d->ksplit <= 1 && !has1 &&
+                        d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 && d->c0k >= 4 && d->c0k <= 24 && d->kh >= 1 &&
+                        d->kw >= 1 && d->dil == 1 && d->qh % 8 == 0 && d->qw % 16 == 0 && nunits <= 160 &&
+                        d->k_pad >= d->kh * d->kw * d->c0k && (d->q_oy | d->q_ox) == 0 && !d->tile_list &&
+                        getenv("FUSG_NO_HALO") == nullptr;
+        if (ok) {
+            TapUnitK h;
+            memset(&h, 0, sizeof(h));
+            h.c = k;
+            h.stride = d->stride; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
+            h.HH = 7 * d->stride + d->kh; h.HW = 15 * d->stride + d->kw;
+            h.CP = d->c0k; h.PP = d->c0k;
+            h.RP = (h.HW * h.PP + 127) / 128 * 128;               // rows 256 B apart: conflict-free 16-lane read groups
+            h.nunits = nunits; h.nsteps = (nunits + 16 / unit - 1) / (16 / unit);
+            h.wfrag = (const _Float16*)d->wfrag;
+            h.nt32 = d->cout_pad / 32;
+            const int upp = d->c0k / unit;
+            for (int j = 0; j < nunits; ++j) {
+                const int tap = j / upp, u = j - tap * upp, ky = tap / d->kw, kx = tap - ky * d->kw;
+                h.uoff[j] = ky * h.RP + kx * h.PP + u * unit;
+            }
+            const int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+            h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
+            h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
+            h.c.ksplit = 1;
+            if (tapunit_lds_bytes(h.HH, h.RP) <= 80 * 1024) {
+                dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
+                e = bn == 128 ? launch_tapunit_128(h, hgrid, s, pk, unit) : bn == 64 ? launch_tapunit_64(h, hgrid, s, pk, unit)
+                                                                                     : launch_tapunit_32(h, hgrid, s, pk, unit);
+                if (e != hipSuccess) { set_error("conv2d tap-unit launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+                note_conv_kernel(FUSG_CONV_TAPUNIT);
+                prof_end(0, s);
+                return FUSG_OK;
+            }
+        }
+    }
     if (halo_ok) {
         HaloK h;
         memset(&h, 0, sizeof(h));

@@ -1,0 +1,239 @@
+// Split-fp16 convolution for layers with very few input channels (the 7x7 stems: ICN 21, EdgeConnect 3 / 4,
+// hourglass 3 channels; stride 1 or 2).
+//
+// The halo kernel walks K as (tap, 32-channel chunk): with 21 channels a third of its MFMAs multiply padding,
+// and with 3-4 channels it does not apply at all, which leaves the generic gather (49 taps x one 16-byte load
+// per row and tap: 70-100 TFLOP/s on layers that should run at the HBM rate).  Here the whole halo of the
+// 8 x 16 output patch - every channel, padded only to a multiple of 4 - is staged ONCE in LDS as fp16 (hi, lo),
+// and K is walked in *units* of U = 8 (channels % 8 == 0) or 4 halves: K index = (tap, unit of the pixel), 16/U
+// units per MFMA k-step.  A lane's 8 k-values of a step are one (U = 8) or two (U = 4) units, each a contiguous
+// LDS read at pixel offset + uoff[unit]; the table of unit offsets comes in through the kernel arguments.
+// ICN stem: 49 taps x 3 units = 147 units = 74 k-steps instead of 98; EdgeConnect / hourglass stems: 13 k-steps.
+// Weights: pack.py stores them per k-step in MFMA-fragment order (frag_tapunit), zero where a unit is padding.
+#pragma once
+#include "conv_kernel_halo.h"
+
+namespace fusg {
+
+struct TapUnitK {
+    ConvK c;
+    int HH, HW;                 // halo extent in input pixels
+    int PP, RP;                 // LDS pitch of a pixel / of a halo row, in halves
+    int CP;                     // staged channels per pixel (multiple of 4, <= 24)
+    int pad_h, pad_w, stride;
+    int tiles_x, tiles_per_img;
+    int nunits, nsteps;         // real units, k-steps = ceil(nunits / (16 / U))
+    const _Float16* wfrag;      // [step][cout_pad/32][hi|lo][64 lanes][8] halves
+    int nt32;
+    int uoff[160];              // LDS offset (halves) of each unit relative to the output pixel's halo origin
+};
+
+template <int TM, int TN, int WM, int WN, int PK, int U>
+__global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
+    const ConvK& p = hk.c;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int BN = 32 * TN * WN;
+    static_assert(BM == 128 && WM * WN == 4 && (U == 8 || U == 4), "8x16 pixel patch, 4 waves");
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    _Float16* Ah = smem_h;                         // [HH][RP]
+    _Float16* Al = Ah + hk.HH * hk.RP;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = tile % p.NT;
+    const int mt = tile / p.NT;
+    const int b = mt / hk.tiles_per_img;
+    const int t2 = mt - b * hk.tiles_per_img;
+    const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+
+    // ---- stage the halo: every (pixel, 4-channel group) item is loaded, pre-processed, split and stored once
+    {
+        const int ipp = hk.CP >> 2;                                // items per pixel
+        const int nitems = hk.HH * hk.HW * ipp;
+        const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
+        const long img_pix0 = (long)b * p.H * p.W;
+        for (int item = t; item < nitems; item += 256) {
+            const int pix = item / ipp, kc = item - pix * ipp;
+            const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
+            int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
+            bool ok = true;
+            if (p.pad_mode == FUSG_PAD_REFLECT) {
+                vy = vy < 0 ? -vy : (vy >= p.H ? 2 * p.H - 2 - vy : vy);
+                vx = vx < 0 ? -vx : (vx >= p.W ? 2 * p.W - 2 - vx : vx);
+                // halo pixels no output of the image uses can fall outside a single reflection: keep them in range
+                vy = min(max(vy, 0), p.H - 1); vx = min(max(vx, 0), p.W - 1);
+            } else if (p.pad_mode == FUSG_PAD_REPLICATE) {
+                vy = min(max(vy, 0), p.H - 1); vx = min(max(vx, 0), p.W - 1);
+            } else {
+                ok = (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+            }
+            const float* ptr = ok ? p.src0 + (img_pix0 + (long)vy * p.W + vx) * p.Cs0 + kc * 4 : p.zeros;
+            f32x4 v = *(const f32x4*)ptr;
+            if (PK == PK_ELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
+            } else if (PK == PK_AFFINE) {
+                const long o = (long)b * p.pre_bstride + kc * 4;
+                const f32x4 sc = *(const f32x4*)(p.pre_scale + o), sh = *(const f32x4*)(p.pre_shift + o);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
+            }
+            h4 hi, lo;
+            split4(v, lo_bound, hi, lo);
+            const int off = hy * hk.RP + hx * hk.PP + kc * 4;
+            *(h4*)(Ah + off) = hi;
+            *(h4*)(Al + off) = lo;
+        }
+    }
+
+    // this wave's weight fragments: column tiles (nt*BN/32 + wn*TN + j), j < TN
+    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 2 * 64 + lane) * 8;
+    const long wstep = (long)hk.nt32 * 2 * 64 * 8;                 // halves per k-step slab
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * TM * 32 + i * 32 + (lane & 31);
+        abase[i] = (row >> 4) * hk.stride * hk.RP + (row & 15) * hk.stride * hk.PP;
+    }
+    const int g = lane >> 5;
+
+    struct BFrag { h8 f[TN][2]; };
+    auto b_load = [&](BFrag& F, int step) {
+        const _Float16* base = wfr + (long)step * wstep;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) F.f[j][hl] = *(const h8*)(base + (j * 2 + hl) * 512);
+    };
+    BFrag bfA, bfB;
+    b_load(bfA, 0);
+    __syncthreads();                                               // halo staged
+
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto compute = [&](int step, const BFrag& F) {
+        h8 ah[TM], al[TM];
+        // unit indices are wave-uniform per half-wave: fetch both halves' offsets with scalar loads, select by lane half
+        if (U == 8) {
+            const int ja = step * 2, jb = ja + 1;
+            const int offa = hk.uoff[min(ja, hk.nunits - 1)], offb = hk.uoff[min(jb, hk.nunits - 1)];
+            const bool live = (g ? jb : ja) < hk.nunits;
+            const int off = g ? offb : offa;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = live ? *(const h8*)(Ah + abase[i] + off) : zero8;
+                al[i] = live ? *(const h8*)(Al + abase[i] + off) : zero8;
+            }
+        } else {
+            const int j = step * 4, last = hk.nunits - 1;
+            const int o0 = hk.uoff[min(j, last)], o1 = hk.uoff[min(j + 1, last)], o2 = hk.uoff[min(j + 2, last)],
+                      o3 = hk.uoff[min(j + 3, last)];
+            const bool l0 = (j + 2 * g) < hk.nunits, l1 = (j + 2 * g + 1) < hk.nunits;
+            const int oa = g ? o2 : o0, ob = g ? o3 : o1;
+            const h4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const h4 a0 = l0 ? *(const h4*)(Ah + abase[i] + oa) : zero4, a1 = l1 ? *(const h4*)(Ah + abase[i] + ob) : zero4;
+                const h4 c0 = l0 ? *(const h4*)(Al + abase[i] + oa) : zero4, c1 = l1 ? *(const h4*)(Al + abase[i] + ob) : zero4;
+                ah[i] = h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                al[i] = h8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            }
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i], F.f[j][term == 1 ? 1 : 0],
+                                                                       acc[i][j], 0, 0, 0);
+    };
+    int step = 0;
+    for (; step + 1 < hk.nsteps; step += 2) {
+        b_load(bfB, step + 1);
+        compute(step, bfA);
+        if (step + 2 < hk.nsteps) b_load(bfA, step + 2);
+        compute(step + 1, bfB);
+    }
+    if (step < hk.nsteps) compute(step, bfA);
+
+    // ---------------------------------------------------------------- epilogue (same as the halo kernel's)
+    const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    if (p.vec_epi) {
+        __syncthreads();
+        float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
+        const int rwave = wm * TM * 32;
+        epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, [&](int row, PixOff& po) {
+            const int rr = rwave + row;
+            pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
+            return true;
+        }, [&](int i) -> float* {
+            return p.stats + ((long)b * p.stats_slots + t2 * 4 + (rwave >> 5) + i) * p.Cout * 2;
+        });
+        return;
+    }
+    PixOff co[TN];
+    float bias[TN];
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        nok[j] = n < p.Cout;
+        bias[j] = p.bias[n];
+        chan_offsets(p, n, co[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            PixOff po;
+            pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+        }
+}
+
+inline size_t tapunit_lds_bytes(int HH, int RP) { return (size_t)2 * HH * RP * sizeof(_Float16); }
+
+template <int TM, int TN, int WM, int WN>
+hipError_t launch_tapunit(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, int unit) {
+    size_t lds = tapunit_lds_bytes(k.HH, k.RP);
+    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
+    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    const void* fn = nullptr;
+#define FUSG_PICK_U(PKV)                                                                      \
+    fn = unit == 8 ? (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 8> : (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 4>;
+    if (pk == PK_NONE) { FUSG_PICK_U(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_U(PK_ELU) } else { FUSG_PICK_U(PK_AFFINE) }
+#undef FUSG_PICK_U
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) return e;
+    TapUnitK kk = k;
+    void* args[] = {(void*)&kk};
+    return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
+}
+
+hipError_t launch_tapunit_128(const TapUnitK&, dim3, hipStream_t, int, int);
+hipError_t launch_tapunit_64(const TapUnitK&, dim3, hipStream_t, int, int);
+hipError_t launch_tapunit_32(const TapUnitK&, dim3, hipStream_t, int, int);
+
+}  // namespace fusg

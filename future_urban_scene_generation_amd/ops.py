@@ -208,7 +208,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         d.pad_h, d.pad_w = plan.pad, (plan.pad if plan.pad_w < 0 else plan.pad_w)
         if dev.get("wfrag") is not None:
             d.wfrag = dev["wfrag"].data_ptr()
-            d.wfrag_order = 1 if plan.s2d_ok() else 0
+            d.wfrag_order = 1 if plan.s2d_ok() else (2 if plan.tapunit_ok() else 0)
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None
@@ -236,7 +236,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
 
 def last_conv_kernel() -> int:
     """Kernel family of the last conv launch issued by this thread (fusg_last_conv_kernel): 0 generic fp32,
-    1 generic split-fp16, 2 halo, 3 halo in parity-quadrant (stride-2) form."""
+    1 generic split-fp16, 2 halo, 3 halo in parity-quadrant (stride-2) form, 4 tap-unit kernel (few-channel stems)."""
     return int(L.lib().fusg_last_conv_kernel())
 
 

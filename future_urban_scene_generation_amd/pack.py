@@ -61,6 +61,8 @@ class ConvPlan:
             frag = frag_f16x3(wsplit, self) if self.nphase == 1 else None
             if frag is not None and self.s2d_ok():
                 frag = frag[s2d_tap_order(self.kh)].contiguous()       # slabs in (parity quadrant, local tap) order
+            if frag is None and self.tapunit_ok():
+                frag = frag_tapunit(wsplit, self)                      # few-channel k x k layer: per-k-step order
             self.dev["wfrag"] = None if frag is None else frag.to(device).contiguous()
         return self
 
@@ -73,6 +75,16 @@ class ConvPlan:
         return (self.nphase == 1 and self.stride == 2 and self.kh == self.kw and self.kh in (3, 4) and self.pad == 1
                 and self.dil == 1 and self.upsample == 0 and self.pad_w < 0 and self.c1k == 0 and self.c0k % 32 == 0
                 and self.c0k > 0)
+
+    def tapunit_ok(self) -> bool:
+        """Few-channel k x k layer (the 7x7 stems) whose weights are stored for the tap-unit kernel
+        (fusg_conv_desc.wfrag_order = 2, csrc/conv_kernel_tapunit.h)."""
+        import os
+        taps = self.kh * self.kw
+        unit = 8 if self.c0k % 8 == 0 else 4
+        return (not os.environ.get("FUSG_NO_TAPUNIT") and self.nphase == 1 and taps >= 9 and self.c1k == 0
+                and 4 <= self.c0k <= 24 and self.dil == 1 and self.upsample == 0 and self.stride in (1, 2)
+                and self.k_pad >= taps * self.c0k and taps * (self.c0k // unit) <= 160 and self.rowsplit is None)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         """q-space output grid for an input of h x w."""
@@ -122,6 +134,22 @@ def s2d_quadrant_taps(k: int):
 def s2d_tap_order(k: int) -> List[int]:
     """Order of the k*k taps (row-major index ky*k + kx) in the parity-quadrant weight layout."""
     return [ky * k + kx for quad in s2d_quadrant_taps(k) for ky, kx, _, _ in quad]
+
+
+def frag_tapunit(wsplit: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:
+    """Weights of a few-channel layer in the k-step order of the tap-unit kernel: K index = (tap, unit of `unit`
+    channels), 16 / unit units per MFMA k-step -> [step][cout_pad/32][hi|lo][64 lanes][8 halves] with
+    lane = (k >> 3 & 1) * 32 + column; k-values past the last unit are zero."""
+    w = wsplit[0]                                               # [2, cout_pad, k_pad], K order (tap, channel) with c0k per tap
+    taps, c = plan.kh * plan.kw, plan.c0k
+    k = taps * c
+    nsteps = (k + 15) // 16
+    wk = torch.zeros(2, plan.cout_pad, nsteps * 16, dtype=w.dtype)
+    wk[:, :, :k] = w[:, :, :k]
+    nt32 = plan.cout_pad // 32
+    wk = wk.view(2, nt32, 32, nsteps, 2, 8)                     # hl, nt, r, step, h, j
+    wk = wk.permute(3, 1, 0, 4, 2, 5)                           # step, nt, hl, h, r, j
+    return wk.reshape(nsteps, nt32, 2, 64, 8).contiguous()
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):

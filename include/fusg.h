@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 103
+#define FUSG_VERSION 104
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -145,7 +145,10 @@ typedef struct fusg_conv_desc {
                                     channels % 32 == 0, even H and W): slabs grouped by the parity quadrant of the input
                                     they read (pack.py: s2d_tap_order) - the launch then runs as four stride-1
                                     convolutions of the quarter-size parity sub-images (halo kernel, 32-channel
-                                    chunks, unit-stride LDS reads) instead of the strided form              */
+                                    chunks, unit-stride LDS reads) instead of the strided form.
+                                    2 (one source with 4..24 channels, dil 1, k x k taps): wfrag holds the weights per
+                                    16-k step of the tap-unit kernel (pack.py: frag_tapunit) - the whole few-channel
+                                    halo is staged once and K runs over (tap, 8- or 4-channel unit)              */
     /* Halo kernel only: the (hi, lo) fp16 weights again, in MFMA-fragment order
      * [tap][chunk32][cout_pad/32][k-half][hi|lo][64 lanes][8 halves] (pack.py: frag_f16x3), so that a
      * B operand is one contiguous 1 KiB wave load.  NULL disables the halo kernel. */
@@ -245,8 +248,10 @@ int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_ten
 int         fusg_version(void);
 const char* fusg_last_error(void);
 /* Kernel family of this thread's last fusg_conv2d launch (tests assert that the intended path ran):
- * 0 generic fp32, 1 generic split-fp16, 2 halo, 3 halo in parity-quadrant form (stride 2); -1 none yet. */
-enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3 };
+ * 0 generic fp32, 1 generic split-fp16, 2 halo, 3 halo in parity-quadrant form (stride 2), 4 tap-unit kernel
+ * (few-channel stems); -1 none yet. */
+enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3,
+       FUSG_CONV_TAPUNIT = 4 };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their

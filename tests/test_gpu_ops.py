@@ -203,6 +203,39 @@ def test_conv_q_window():
         ops.conv(plan, _nhwc(x), out=out, q_window=(0, 0, H + 1, W))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,pm,H,W", [(21, 64, 7, 1, 3, 1, 16, 32), (3, 64, 7, 2, 3, 0, 32, 64),
+                                                           (4, 64, 7, 1, 3, 1, 8, 16), (12, 32, 3, 1, 1, 0, 16, 16),
+                                                           (21, 128, 5, 1, 2, 0, 24, 32)])
+def test_conv_tapunit_stems(cin, cout, k, stride, pad, pm, H, W, precision):
+    """Few-channel k x k layers (the 7x7 stems) on the tap-unit kernel: whole halo staged once, K walked in 8- or
+    4-channel units; with the pre-op kinds; and that this IS the path that runs on the split-fp16 side."""
+    x = _rand(2, cin, H, W, seed=1)
+    w = _rand(cout, cin, k, k, seed=2, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=3)
+    plan = pack.pack_conv(w, b, stride=stride, pad=pad, pad_mode=pm)
+    assert plan.tapunit_ok()
+    xd = ops.as_nhwc(x.to(dev()), cpad=plan.c0k)
+
+    def ref_of(xx):
+        xin = F.pad(xx, (pad,) * 4, mode="reflect") if pm else F.pad(xx, (pad,) * 4)
+        return F.conv2d(xin, w, b, stride=stride)
+
+    got = ops.conv(plan, xd, ksplit=1)
+    assert ops.last_conv_kernel() == (4 if precision == "f16x3" else 0)
+    _close(got, ref_of(x))
+    _close(ops.conv(plan, xd, ksplit=1, pre_op=L.PRE_ELU), ref_of(F.elu(x)))
+    sc, sh = torch.rand(2, plan.c0k, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(2, plan.c0k, seed=5) * 0.2
+    xa = torch.relu(x * sc[:, :cin, None, None] + sh[:, :cin, None, None])
+    got = ops.conv(plan, xd, ksplit=1, pre_op=L.PRE_AFFINE_RELU, pre=(sc.to(dev()).contiguous(), sh.to(dev()).contiguous()),
+                   pre_bstride=plan.c0k)
+    _close(got, ref_of(xa))
+    out, (isc, ish) = ops.conv_in(plan, xd, ksplit=1)                   # fused InstanceNorm statistics (ICN / EC stems)
+    r = ref_of(x)
+    rstd = (r.var(dim=(2, 3), unbiased=False) + 1e-5).rsqrt()
+    _close(isc, rstd, rtol=2e-4, atol=2e-4)
+    _close(ish, -r.mean(dim=(2, 3)) * rstd, rtol=2e-4, atol=5e-4)
+
+
 def test_conv_tile_list_and_replicate_pad(precision):
     """PAD_REPLICATE = edge clamp on every conv path; tile_list computes only the listed 8x16 patches (halo kernel)."""
     x = _rand(2, 32, 24, 48, seed=1)
