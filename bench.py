@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--settle-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (DVFS settle)")
     ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
@@ -163,6 +164,17 @@ def main():
     sampler = PowerSampler() if (rank == 0 and world == 1) else None
     if sampler:
         sampler.start()
+    # Clock settle, before (and on top of) the W warm-up steps: the card's DVFS needs ~0.5 s of load to reach its
+    # steady operating point (a burst right after start-up reads 5-20 % slow or fast), and lazy
+    # initialisation (plan upload, stream creation, RCCL communicators) happens in the first step.
+    step()                                             # lazy initialisation
+    torch.cuda.synchronize()
+    settle = 1
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < args.settle_s:
+        step()
+        torch.cuda.synchronize()
+        settle += 1
     for _ in range(args.warmup):
         step()
     barrier()
@@ -288,6 +300,7 @@ def main():
         line.update(extra)
         if power is not None:
             line["power"] = power
+        line["settle_steps"] = settle
         line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch"
         print(json.dumps(line), flush=True)
     if world > 1:
