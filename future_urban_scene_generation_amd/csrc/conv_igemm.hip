@@ -275,7 +275,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
             h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
             h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
             h.c.ksplit = 1;
-            if (tapunit_lds_bytes(h.HH, h.RP) <= 80 * 1024) {
+            if (tapunit_lds_bytes(h.HH, h.RP) <= 80 * 1024 && h.HH * h.HW * (h.CP / 4) <= 256 * 8) {
                 dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
                 e = bn == 128 ? launch_tapunit_128(h, hgrid, s, pk, unit) : bn == 64 ? launch_tapunit_64(h, hgrid, s, pk, unit)
                                                                                      : launch_tapunit_32(h, hgrid, s, pk, unit);

@@ -56,43 +56,59 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
     const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
     const int oy0 = ty * 8, ox0 = tx * 16;
 
-    // ---- stage the halo: every (pixel, 4-channel group) item is loaded, pre-processed, split and stored once
+    // ---- stage the halo: every (pixel, 4-channel group) item is loaded, pre-processed, split and stored once.
+    // All of a thread's loads (<= 8) are issued before the first is consumed.
     {
+        constexpr int NI = 8;
         const int ipp = hk.CP >> 2;                                // items per pixel
-        const int nitems = hk.HH * hk.HW * ipp;
+        const int nitems = hk.HH * hk.HW * ipp;                    // <= 256 * NI (checked on the host)
         const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
         const long img_pix0 = (long)b * p.H * p.W;
-        for (int item = t; item < nitems; item += 256) {
-            const int pix = item / ipp, kc = item - pix * ipp;
-            const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
-            int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
-            bool ok = true;
-            if (p.pad_mode == FUSG_PAD_REFLECT) {
-                vy = vy < 0 ? -vy : (vy >= p.H ? 2 * p.H - 2 - vy : vy);
-                vx = vx < 0 ? -vx : (vx >= p.W ? 2 * p.W - 2 - vx : vx);
-                // halo pixels no output of the image uses can fall outside a single reflection: keep them in range
-                vy = min(max(vy, 0), p.H - 1); vx = min(max(vx, 0), p.W - 1);
-            } else if (p.pad_mode == FUSG_PAD_REPLICATE) {
-                vy = min(max(vy, 0), p.H - 1); vx = min(max(vx, 0), p.W - 1);
-            } else {
-                ok = (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+        f32x4 hreg[NI];
+        int hoff[NI];
+        unsigned hvalid = 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int item = t + 256 * j;
+            hoff[j] = -1;
+            hreg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (item < nitems) {
+                const int pix = item / ipp, kc = item - pix * ipp;
+                const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
+                int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
+                bool ok = true;
+                if (p.pad_mode == FUSG_PAD_ZERO) {
+                    ok = (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+                } else if (p.pad_mode == FUSG_PAD_REFLECT) {
+                    vy = vy < 0 ? -vy : (vy >= p.H ? 2 * p.H - 2 - vy : vy);
+                    vx = vx < 0 ? -vx : (vx >= p.W ? 2 * p.W - 2 - vx : vx);
+                }
+                vy = min(max(vy, 0), p.H - 1); vx = min(max(vx, 0), p.W - 1);       // (also the replicate mode)
+                hoff[j] = hy * hk.RP + hx * hk.PP + kc * 4;
+                if (ok) hvalid |= 1u << j;
+                const float* ptr = ok ? p.src0 + (img_pix0 + (long)vy * p.W + vx) * p.Cs0 + kc * 4 : p.zeros;
+                hreg[j] = *(const f32x4*)ptr;
             }
-            const float* ptr = ok ? p.src0 + (img_pix0 + (long)vy * p.W + vx) * p.Cs0 + kc * 4 : p.zeros;
-            f32x4 v = *(const f32x4*)ptr;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (hoff[j] < 0) continue;
+            f32x4 v = hreg[j];
             if (PK == PK_ELU) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
             } else if (PK == PK_AFFINE) {
-                const long o = (long)b * p.pre_bstride + kc * 4;
+                const int kc4 = ((t + 256 * j) % ipp) * 4;          // channel offset of the item
+                const long o = (long)b * p.pre_bstride + kc4;
                 const f32x4 sc = *(const f32x4*)(p.pre_scale + o), sh = *(const f32x4*)(p.pre_shift + o);
+                const bool ok = (hvalid >> j) & 1u;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
             h4 hi, lo;
             split4(v, lo_bound, hi, lo);
-            const int off = hy * hk.RP + hx * hk.PP + kc * 4;
-            *(h4*)(Ah + off) = hi;
-            *(h4*)(Al + off) = lo;
+            *(h4*)(Ah + hoff[j]) = hi;
+            *(h4*)(Al + hoff[j]) = lo;
         }
     }
 
