@@ -221,7 +221,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         # back to the separate streaming pass
         if (d.ksplit <= 1 and plan.nphase == 1 and store == L.STORE_NORMAL and act == L.ACT_NONE and res0 is None
                 and res1 is None and (qh * qw) % 32 == 0 and plan.cout % 4 == 0 and out_c_off % 4 == 0 and is_nhwc(out)
-                and out.stride(3) % 4 == 0):
+                and out.stride(3) % 4 == 0 and _os.environ.get("FUSG_NO_VEC_EPI") is None):
             stats = torch.empty((b, qh * qw // 32, plan.cout, 2), device=x0.device, dtype=torch.float32)
             d.stats_out = stats.data_ptr()
     if stats_into is not None:
@@ -295,7 +295,8 @@ def conv_transpose_phases(phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, 
     cout = phases[0].cout
     out = nhwc_empty(b, cout, 2 * h, 2 * w, x.device)
     n = h * w // 32
-    fuse = (want_stats and act == L.ACT_NONE and (h * w) % 32 == 0 and cout % 4 == 0)
+    fuse = (want_stats and act == L.ACT_NONE and (h * w) % 32 == 0 and cout % 4 == 0
+            and _os.environ.get("FUSG_NO_VEC_EPI") is None)
     stats = torch.empty((b, 4 * n, cout, 2), device=x.device, dtype=torch.float32) if fuse else None
     for ph, plan in enumerate(phases):
         conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), q_size=(h, w), pre_op=pre_op, pre=pre,
