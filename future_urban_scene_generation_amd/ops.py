@@ -265,7 +265,7 @@ def up2_phases_ok(x: torch.Tensor, precision: Optional[str] = None) -> bool:
 def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
              precision: Optional[str] = None) -> torch.Tensor:
     """nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv.  `exact` = the 25-tap plan with the upsample fused into its
-    gather (pack_conv(..., upsample=1)); `phases` = pack_conv_up2_phases of the same filter.  When the shapes qualify,
+    gather (pack_conv(..., upsample=1)); `phases` = pack_conv_up2_d2s (one launch) or pack_conv_up2_phases (four) of the same filter.  When the shapes qualify,
     four 3x3 phase launches on the low-res input (9 MACs per output instead of 25) write the interleaved output and
     the 25-tap form then recomputes the outermost ring of pixels, the only place the two differ
     (pack.up2_phase_weights)."""
@@ -276,9 +276,13 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     # split-K launches do not use the halo kernel: keep K whole where the phase launches qualify for it
     halo = ((precision or PRECISION) == "f16x3" and c % 32 == 0 and h % 8 == 0 and w % 16 == 0
             and _os.environ.get("FUSG_NO_HALO") is None)
-    for ph, plan in enumerate(phases):
-        conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
+    if isinstance(phases, ConvPlan):                               # all four phases in one launch, DepthToSpace store
+        conv(phases, x, out=out, store=L.STORE_D2S, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
              precision=precision, ksplit=1 if halo else 0)
+    else:
+        for ph, plan in enumerate(phases):
+            conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre,
+                 pre_bstride=pre_bstride, precision=precision, ksplit=1 if halo else 0)
     # the outermost ring of output pixels, with the 25-tap form: four one-pixel-wide windows of the full convolution
     for win in ((0, 0, 1, 2 * w), (2 * h - 1, 0, 1, 2 * w), (0, 0, 2 * h, 1), (0, 2 * w - 1, 2 * h, 1)):
         conv(exact, x, out=out, q_window=win, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)

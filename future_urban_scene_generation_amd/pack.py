@@ -240,6 +240,17 @@ def up2_phase_weights(weight: torch.Tensor) -> List[torch.Tensor]:
     return out
 
 
+def pack_conv_up2_d2s(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> ConvPlan:
+    """The four phase convolutions of up2_phase_weights stacked along the output channels - phase 2*py+px in channel
+    block [(2*py+px)*cout, +cout) - as ONE 3x3 conv (edge-replicate padding 1) whose DepthToSpace store
+    (FUSG_STORE_D2S, the VUnet's DCR order) interleaves the phases: the low-res halo is staged once for all four
+    phases and the column tiles are 128 wide even for cout = 64."""
+    from . import _lib as L
+    ws = torch.cat(up2_phase_weights(weight), dim=0)                       # [4*cout, cin, 3, 3]
+    bs = None if bias is None else bias.detach().to("cpu", torch.float32).repeat(4)
+    return pack_conv(ws, bs, stride=1, pad=1, pad_mode=L.PAD_REPLICATE)
+
+
 def pack_conv_up2_phases(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> List[ConvPlan]:
     """The four 3x3 phase convolutions of up2_phase_weights as ConvPlans (edge-replicate padding 1)."""
     from . import _lib as L

@@ -131,10 +131,12 @@ class G_Resnet(FusedNet):
         for i in range(nd):
             blk = dec[2 + 2 * i]
             P["up"].append(self._pack_block(blk, device, upsample=1))
-            # 5x5 reflect-padded conv after a 2x nearest upsample: also packed as four 3x3 phase convolutions of
-            # the low-res input (pack.up2_phase_weights: 2.8x fewer MACs); ops.conv_up2 picks the route per input
+            # 5x5 reflect-padded conv after a 2x nearest upsample: also packed as the four 3x3 phase convolutions of
+            # the low-res input (pack.up2_phase_weights: 2.8x fewer MACs), stacked into one launch whose DepthToSpace
+            # store interleaves the phases; ops.conv_up2 picks the route per input
             ok = blk.kernel_size == 5 and blk.padding == 2 and blk.stride == 1 and blk.pad_type == "reflect"
-            P["up_phases"].append([q.to(device) for q in pack.pack_conv_up2_phases(blk.conv.weight, blk.conv.bias)] if ok else None)
+            ok = ok and blk.conv.weight.shape[0] % 4 == 0
+            P["up_phases"].append(pack.pack_conv_up2_d2s(blk.conv.weight, blk.conv.bias).to(device) if ok else None)
             P["ln"].append((dev_vec(blk.norm.gamma, device), dev_vec(blk.norm.beta, device), blk.norm.eps))
         return P
 

@@ -156,6 +156,8 @@ def test_conv_up2_phases(B, cin, cout, H, W, precision):
     got = ops.conv_up2(exact, phases, xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)
     assert tuple(got.shape) == tuple(ref.shape)
     _close(got, ref)
+    got = ops.conv_up2(exact, pack.pack_conv_up2_d2s(w, b), xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)
+    _close(got, ref)                                              # the four phases as one launch with a D2S store
 
 
 @pytest.mark.parametrize("cin,cout,k,pm,H,W", [(64, 128, 4, 1, 32, 64), (64, 128, 4, 0, 32, 64), (32, 64, 3, 0, 32, 64),
