@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--vehicles", type=int, default=0,
+                    help="strong scaling: this many vehicles in total, sharded over the ranks (default: --batch per rank, weak)")
     ap.add_argument("--settle-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (DVFS settle)")
     ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
     ap.add_argument("--res", type=int, default=256)
@@ -142,11 +144,20 @@ def main():
 
     torch.set_grad_enabled(False)
     pipe = VehiclePipeline(dev, inpaint=args.inpaint)
-    batch = synth_batch(args.batch, args.res, dev, inpaint=args.inpaint, seed=rank)
-    n_total = args.batch * world
+    if args.vehicles:
+        # strong scaling (BASELINE configs[3]: one frame's vehicles sharded over the ranks): this rank's contiguous shard
+        from future_urban_scene_generation_amd.pipeline import shard_range
+        lo, hi = shard_range(args.vehicles, rank, world)
+        args.batch, n_total, first = hi - lo, args.vehicles, lo
+        full = synth_batch(args.vehicles, args.res, "cpu", inpaint=args.inpaint, seed=0)
+        batch = {k: v[lo:hi].to(dev) for k, v in full.items()}
+        del full
+    else:
+        batch = synth_batch(args.batch, args.res, dev, inpaint=args.inpaint, seed=rank)
+        n_total, first = args.batch * world, rank * args.batch
     # VUnet noise: one stream per vehicle, seeded by the vehicle's global index, so that the images do not depend
     # on how the vehicles are spread over ranks
-    seeds = [1000 + rank * args.batch + i for i in range(args.batch)]
+    seeds = [1000 + first + i for i in range(args.batch)]
 
     def step():
         out = pipe.run(batch, vehicle_seeds=seeds)
@@ -287,13 +298,14 @@ def main():
     if rank == 0:
         line = {"metric": "synthesised vehicle crops/sec @%dx%d" % (args.res, args.res), "value": round(crops_per_s, 3), "unit": "crops/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.vehicles else "weak",
                 "vs_baseline": None,
                 "dtype": "f32" if prec == "f32" else "f32 operands as 3x f16 split products, f32 accumulate (fp32-class accuracy)",
                 "data": "synthetic",
                 "config": {"workload": ("configs[2]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
                                         if args.inpaint else
-                                        "configs[1]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % (args.batch, args.res, args.res),
+                                        "configs[1]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % (args.batch, args.res, args.res)
+                                       + (" | strong scaling: %d vehicles of one frame sharded over the ranks (configs[3])" % args.vehicles if args.vehicles else ""),
                            "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint), "precision": prec,
                            "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
