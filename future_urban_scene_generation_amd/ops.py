@@ -22,6 +22,13 @@ _DT = {torch.float32: L.F32, torch.uint8: L.U8, torch.int32: L.I32}
 # "f16x3" = split-fp16 (fp32-class accuracy, 3 passes at the fp16 matrix rate).  Process-wide default,
 # overridable per call; FUSG_PRECISION in the environment sets the initial value.
 import os as _os
+
+
+def _env_set(name: str) -> bool:
+    """Development switch read from the environment (per call: tests and bench flip some of them at run time)."""
+    return name in _os.environ
+
+
 _PREC = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
 PRECISION = _os.environ.get("FUSG_PRECISION", "f16x3")
 
@@ -39,15 +46,25 @@ def _require_gpu(t: torch.Tensor, what: str = "input") -> None:
                            "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream on the current device (the fast C accessor when this torch has
+    it: `torch.cuda.current_stream()` costs ~4 us of Python per call, and there are ~370 launches per pass)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
+_NO_TENSOR = L.Tensor()
+
+
 def desc(t: Optional[torch.Tensor]) -> L.Tensor:
-    """fusg_tensor for a 4-D torch tensor (or an absent tensor)."""
-    d = L.Tensor()
+    """fusg_tensor for a 4-D torch tensor (or an absent tensor: a shared all-zero struct, never written to)."""
     if t is None:
-        return d
+        return _NO_TENSOR
+    d = L.Tensor()
     assert t.dim() == 4, t.shape
     d.data = t.data_ptr()
     d.n, d.c, d.h, d.w = t.shape
@@ -208,7 +225,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         d.pad_h, d.pad_w = plan.pad, (plan.pad if plan.pad_w < 0 else plan.pad_w)
         if dev.get("wfrag") is not None:
             d.wfrag = dev["wfrag"].data_ptr()
-            d.wfrag_order = 1 if plan.s2d_ok() else (2 if plan.tapunit_ok() else 0)
+            d.wfrag_order = dev["wfrag_order"]
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None
@@ -221,7 +238,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         # back to the separate streaming pass
         if (d.ksplit <= 1 and plan.nphase == 1 and store == L.STORE_NORMAL and act == L.ACT_NONE and res0 is None
                 and res1 is None and (qh * qw) % 32 == 0 and plan.cout % 4 == 0 and out_c_off % 4 == 0 and is_nhwc(out)
-                and out.stride(3) % 4 == 0 and _os.environ.get("FUSG_NO_VEC_EPI") is None):
+                and out.stride(3) % 4 == 0 and not _env_set("FUSG_NO_VEC_EPI")):
             stats = torch.empty((b, qh * qw // 32, plan.cout, 2), device=x0.device, dtype=torch.float32)
             d.stats_out = stats.data_ptr()
     if stats_into is not None:

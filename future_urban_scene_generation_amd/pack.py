@@ -64,6 +64,7 @@ class ConvPlan:
             if frag is None and self.tapunit_ok():
                 frag = frag_tapunit(wsplit, self)                      # few-channel k x k layer: per-k-step order
             self.dev["wfrag"] = None if frag is None else frag.to(device).contiguous()
+            self.dev["wfrag_order"] = 1 if self.s2d_ok() else (2 if self.tapunit_ok() else 0)   # fusg_conv_desc.wfrag_order
         return self
 
     def s2d_ok(self) -> bool:
