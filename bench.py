@@ -182,7 +182,16 @@ def main():
     torch.cuda.synchronize()
     settle = 1
     t_s = time.perf_counter()
-    while time.perf_counter() - t_s < args.settle_s:
+
+    def keep_settling():
+        # every rank must run the same number of steps (a step contains collectives): rank 0's clock decides
+        go = torch.tensor([1 if time.perf_counter() - t_s < args.settle_s else 0], dtype=torch.int32,
+                          device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
+        if world > 1:
+            dist.broadcast(go, src=0)
+        return bool(go.item())
+
+    while keep_settling():
         step()
         torch.cuda.synchronize()
         settle += 1
