@@ -1,29 +1,41 @@
 #!/usr/bin/env python3
 """Headline benchmark: synthesised 256x256 vehicle crops / second on N MI355X (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One *step* = one pass of the hot path over one batch of synthetic crops per rank:
 hourglass (+argmax) -> ICN -> VUnet first-frame (enc_up, enc_down, dec_up, dec_down) -> uint8
 quantisation [+ EdgeGenerator + InpaintGenerator with --inpaint], then (N > 1) the gather of the
 rendered uint8 crops to rank 0 over RCCL.  The default workload is BASELINE.json configs[1]:
-batch 32 of 256x256 crops per GPU.  fp32 tensors (the reference's dtype) everywhere; the conv
-contraction runs either as exact fp32 MFMA (--precision f32) or, by default, as split-fp16 MFMA with
-fp32-class accuracy (f16x3) - both pass the same parity suite.
-Inputs and weights are synthetic (no datasets / checkpoints in this environment) and resident in
-HBM before the timed region; VUnet's sampler noise is drawn on the CPU generator inside the step,
-as the reference does.  Weak scaling: each rank processes its own batch (vehicles are independent).
+batch 32 of 256x256 crops per GPU.  Tensors are fp32 (the reference's dtype) everywhere.
 
-Extra fields: "roofline" (conv kernels: algorithmic FLOPs of SURVEY.md §8d divided by the kernels'
-HIP-event time on the launch stream, measured live in a second pass of the same K steps),
-"cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's cores
-on a bounded sample of the same workload; N=1, rank 0 only), "ssim_vs_cpu_ref" / "kp_idx_exact"
-(quality of the GPU path on that very sample) and "clip_mode" (secondary figure: 8 vehicles x 6 frames).
+Precision legs.  The conv contraction exists in two arithmetics and ONE run times both, each with the full
+protocol (W warm-up steps, K timed steps between barrier + synchronize, max over ranks, roofline pass):
+  f32   : exact fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain) - the reference's arithmetic.
+  f16x3 : fp32 operands split into scaled fp16 pairs, three fp16 MFMA products, fp32 accumulation
+          (csrc/conv_kernel_h3.h).  Error vs fp64 at or below the f32 kernel's over operand scales 1e-3..1e2
+          (tests/test_gpu_ops.py::test_f16x3_scale_sweep, profiles/r02_parity.json); operands outside the split's
+          range raise a device-side status word and the pass is redone in f32 (never a silent clamp) - the
+          benchmark checks that word once after the timed steps and refuses the leg if it was raised.
+The headline `value` is the f16x3 leg (fp32-class accuracy, defended by the tests above); "precision_legs" carries
+both legs in the same line.  --precision limits the run to one leg.
+
+Inputs and weights are synthetic (no datasets / checkpoints in this environment) and resident in HBM before
+the timed region; VUnet's sampler noise is drawn on the CPU generator inside the step, as the reference does.
+Weak scaling: each rank processes its own batch (vehicles are independent); --vehicles V is the strong-scaling
+mode of BASELINE configs[3] (one frame's V vehicles sharded over the ranks, e.g. --gpus 8 --vehicles 64).
+
+Extra fields: "roofline" (conv kernels: algorithmic FLOPs of SURVEY.md §8d - and the FLOPs as launched - divided
+by the kernels' HIP-event time on the launch stream, measured live in a second pass of the same K steps),
+"cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's cores on a bounded
+sample of the same workload; N=1, rank 0 only), "ssim_vs_cpu_ref" / "kp_idx_exact" (quality of the GPU path on
+that very sample) and "clip_mode" (secondary figure: 8 vehicles x 6 frames).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,24 +47,69 @@ if REPO not in sys.path:
 GFLOP_PER_CROP = {"hg": 17.95, "icn": 130.12, "vunet_first": 76.27, "edge": 96.13, "inpaint": 97.37}
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak (no sparsity)
+DTYPE = {"f32": "f32",
+         "f16x3": "f32 tensors; conv contraction as 3 fp16 MFMA products of scaled (hi, lo) operand splits, f32 accumulate "
+                  "(error vs fp64 <= the f32 MFMA kernel's, range-guarded; exact-f32 leg in precision_legs)"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--vehicles", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3], e.g. 64): this many vehicles in total, sharded over the "
+                         "ranks (default: --batch per rank, weak scaling)")
+    ap.add_argument("--settle-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (DVFS settle)")
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
+    ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
+    ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "both"], default="both",
+                    help="which precision legs to time (default both; the headline is f16x3 when it ran)")
+    return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, as CHILD processes
+    (this parent has not touched HIP and never does - an exec from a GPU-initialised process is forbidden on the
+    pool), wait for them and return the worst exit status.  Rank 0's JSON line goes to the inherited stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:                                              # a rank died: do not leave the others at a barrier
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 class PowerSampler:
     """Socket power / shader clock of the card under test, sampled from sysfs hwmon while the timed steps run.
     The big layers run at the 1400 W board limit, so this is part of reading the number."""
 
-    def __init__(self, device_index=0):
+    def __init__(self, pci_bdf=None):
         import glob
         self.p = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") +
                         glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
-        try:                                        # keep only the card torch is running on (PCI address match)
-            pr = torch.cuda.get_device_properties(device_index)
-            bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-            mine = [x for x in self.p if bdf in os.path.realpath(x.split("/hwmon/")[0])]
+        if pci_bdf:                                 # keep only the card under test (PCI address match)
+            mine = [x for x in self.p if pci_bdf in os.path.realpath(x.split("/hwmon/")[0])]
             if mine:
                 self.p = mine[:1]
-        except Exception:
-            pass
         self.f = [os.path.join(os.path.dirname(x), "freq1_input") for x in self.p]
         self.samples, self._stop, self._th = [], False, None
         self.idle = [self._read(x) for x in self.p]
@@ -89,64 +146,121 @@ class PowerSampler:
         k = max(range(len(self.p)), key=lambda i: avg[i] - self.idle[i])       # the card whose power rose
         return {"avg_w": round(avg[k] / 1e6, 1), "max_w": round(max(s[0][k] for s in self.samples) / 1e6, 1),
                 "sclk_mhz": round(sum(s[1][k] for s in self.samples) / n / 1e6), "samples": n,
-                "source": "sysfs hwmon power1/freq1 of the card under test, 10 ms period, second half of warm-up + timed + roofline legs"}
+                "source": "sysfs hwmon power1/freq1 of the card under test, 10 ms period, second half of the headline leg"}
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_leg(args, batch, pipe, torch):
+    """the CPU oracle (a port of the reference's torch graph) on this host's cores.  Bounded to
+    about a minute: the thread count is chosen by a sweep on a 2-crop sample ({8,16,32,64,all} that exist), then the
+    sample (--cpu-sample crops, batch = sample) is timed warm-up 1 + best of 3 at that count, with per-network
+    seconds.  Returns (cpu_baseline dict, quality dict of the GPU path on the same sample and noise seed)."""
+    import numpy as np
+
+    import oracle
+    from future_urban_scene_generation_amd.pipeline import load_schema
+    from future_urban_scene_generation_amd.synth import synth_state_dict
+    ns = max(1, min(args.cpu_sample, args.batch))
+    sds = {n: synth_state_dict(n, load_schema(n), 0)
+           for n in (("hg", "icn", "vunet") + (("edge", "inpaint") if args.inpaint else ()))}
+    cpu_batch = {k: v[:ns].cpu() for k, v in batch.items()}
+    two = {k: v[:min(2, ns)] for k, v in cpu_batch.items()}
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for nt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu} | {min(ncpu, default_threads)}):
+        torch.set_num_threads(nt)
+        oracle.crop_pass(sds, {k: v[:1] for k, v in two.items()}, args.inpaint)        # warm-up (thread pool, oneDNN primitives)
+        t1 = time.perf_counter()
+        oracle.crop_pass(sds, two, args.inpaint)
+        sweep[nt] = round(len(two["hg_x"]) / (time.perf_counter() - t1), 4)
+    best_nt = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    oracle.crop_pass(sds, {k: v[:1] for k, v in cpu_batch.items()}, args.inpaint)        # warm-up
+    best, best_secs, ref = None, None, None
+    for _ in range(3):
+        secs = {}
+        torch.manual_seed(77)
+        t1 = time.perf_counter()
+        ref = oracle.crop_pass(sds, cpu_batch, args.inpaint, seconds=secs)
+        dt = time.perf_counter() - t1
+        if best is None or dt < best:
+            best, best_secs = dt, secs
+        if best * 3 > 45:                       # keep the leg bounded on slow hosts: one pass is then the figure
+            break
+    torch.set_num_threads(default_threads)
+    base = {"value": round(ns / best, 4), "unit": "crops/s", "cores": best_nt, "kind": "port",
+            "cpu": cpu_model(), "host_cpus": ncpu,
+            "sample": f"{ns} crops of the same workload as one batch of {ns} (the GPU leg runs batch {args.batch}); warm-up 1, "
+                      f"best of 3 passes at the best thread count of a sweep on a 2-crop sample",
+            "thread_sweep_crops_per_s": {str(k): v for k, v in sweep.items()},
+            "seconds_per_net": {k: round(v, 3) for k, v in best_secs.items()}}
+    torch.manual_seed(77)
+    got = pipe.run({k: v[:ns] for k, v in batch.items()})
+    quality = {"ssim_vs_cpu_ref": round(min(oracle.ssim(got["icn_u8"].cpu().numpy(), ref["icn_u8"]),
+                                            oracle.ssim(got["vunet_u8"].cpu().numpy(), ref["vunet_u8"])), 6),
+               "kp_idx_exact": bool(np.array_equal(got["kp_idx"].cpu().numpy(), ref["kp_idx"]))}
+    return base, quality
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=15)
-    ap.add_argument("--vehicles", type=int, default=0,
-                    help="strong scaling: this many vehicles in total, sharded over the ranks (default: --batch per rank, weak)")
-    ap.add_argument("--settle-s", type=float, default=0.6, help="seconds of untimed steps before the warm-up steps (DVFS settle)")
-    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
-    ap.add_argument("--res", type=int, default=256)
-    ap.add_argument("--inpaint", action="store_true", help="BASELINE configs[2]: add EdgeConnect")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
-    ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
-    ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
-    ap.add_argument("--precision", choices=["f16x3", "f32"], default=None,
-                    help="conv contraction: f16x3 = split-fp16 MFMA, fp32-class accuracy (default); f32 = exact fp32 MFMA")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: be the launcher.  Nothing above this line (and nothing in this branch) touches HIP.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FUSG_BENCH_DRYRUN"):             # tests/test_bench_cpu.py: what each started rank was given
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    if os.environ.get("FUSG_DIST_BACKEND", "nccl") != "nccl":          # rehearsal: ranks share the cards that exist
+    backend = os.environ.get("FUSG_DIST_BACKEND", "nccl")
+    if backend != "nccl":                               # rehearsal: ranks share the cards that exist
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         # RCCL ("nccl" on ROCm).  FUSG_DIST_BACKEND=gloo rehearses the multi-rank code path where the ranks have
         # to share one card (development boxes): the gathers are then staged through host memory.
-        backend = os.environ.get("FUSG_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if (world == 1 or backend == "nccl") else "cpu"
 
     from future_urban_scene_generation_amd import ops
-    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, synth_batch
-    if args.precision:
-        ops.set_precision(args.precision)
-    prec = ops.PRECISION
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, shard_range, synth_batch
 
     torch.set_grad_enabled(False)
     pipe = VehiclePipeline(dev, inpaint=args.inpaint)
     if args.vehicles:
         # strong scaling (BASELINE configs[3]: one frame's vehicles sharded over the ranks): this rank's contiguous shard
-        from future_urban_scene_generation_amd.pipeline import shard_range
         lo, hi = shard_range(args.vehicles, rank, world)
         args.batch, n_total, first = hi - lo, args.vehicles, lo
         full = synth_batch(args.vehicles, args.res, "cpu", inpaint=args.inpaint, seed=0)
@@ -158,13 +272,18 @@ def main():
     # VUnet noise: one stream per vehicle, seeded by the vehicle's global index, so that the images do not depend
     # on how the vehicles are spread over ranks
     seeds = [1000 + first + i for i in range(args.batch)]
+    gather_ms = []
 
     def step():
-        out = pipe.run(batch, vehicle_seeds=seeds)
+        # check="async": the range guard's status word is read once, after the timed steps (pipe.finish()), instead of
+        # synchronising the host after every pass
+        out = pipe.run(batch, vehicle_seeds=seeds, check="async")
         if world > 1:                                   # the path's only exchange: crops -> rank 0
+            t_g = time.perf_counter()
             crops = torch.cat([out["icn_u8"], out["vunet_u8"]], dim=-1)
             gather_in_order(crops, n_total)
             gather_in_order(out["kp_idx"], n_total)
+            gather_ms.append((time.perf_counter() - t_g) * 1e3)      # host time of the enqueue (RCCL is asynchronous)
         return out
 
     def barrier():
@@ -172,96 +291,132 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sampler = PowerSampler() if (rank == 0 and world == 1) else None
-    if sampler:
-        sampler.start()
-    # Clock settle, before (and on top of) the W warm-up steps: the card's DVFS needs ~0.5 s of load to reach its
-    # steady operating point (a burst right after start-up reads 5-20 % slow or fast), and lazy
-    # initialisation (plan upload, stream creation, RCCL communicators) happens in the first step.
-    step()                                             # lazy initialisation
-    torch.cuda.synchronize()
-    settle = 1
-    t_s = time.perf_counter()
-
-    def keep_settling():
-        # every rank must run the same number of steps (a step contains collectives): rank 0's clock decides
-        go = torch.tensor([1 if time.perf_counter() - t_s < args.settle_s else 0], dtype=torch.int32,
-                          device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
-        if world > 1:
-            dist.broadcast(go, src=0)
-        return bool(go.item())
-
-    while keep_settling():
-        step()
-        torch.cuda.synchronize()
-        settle += 1
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    # Roofline leg: the SAME K steps again with one HIP-event pair around every conv launch, recorded on
-    # the launch stream.  Kept out of the timed region above because ~460 event records per step cost
-    # ~10 % of wall time; kernel durations themselves are unaffected (rocprofv3 agrees, profiles/).
-    # The branches of the pass are serialised for this leg (FUSG_STREAMS=0): kernels that share the GPU with
-    # another stream's kernels would each read longer than they are.
-    prof = not args.no_prof
-    if prof:
-        streams_env = os.environ.get("FUSG_STREAMS")
-        os.environ["FUSG_STREAMS"] = "0"
-        step()
-        barrier()
-        ops.prof_reset()
-        ops.prof_enable(True)
-        for _ in range(args.steps):
-            step()
-        barrier()
-        ops.prof_enable(False)
-        if streams_env is None:
-            del os.environ["FUSG_STREAMS"]
-        else:
-            os.environ["FUSG_STREAMS"] = streams_env
-    power = sampler.stop() if sampler else None
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    crops_per_s = n_total * args.steps / dt
     scale = (args.res / 256.0) ** 2
     gflop_crop = (GFLOP_PER_CROP["hg"] + GFLOP_PER_CROP["icn"] + GFLOP_PER_CROP["vunet_first"] +
                   ((GFLOP_PER_CROP["edge"] + GFLOP_PER_CROP["inpaint"]) if args.inpaint else 0.0)) * scale
 
-    roofline = None
-    if prof:
-        conv_ms, conv_launches, _ = ops.prof_read(0)
-        alg_flops = gflop_crop * 1e9 * args.batch * args.steps          # this rank's conv work in the timed region
-        achieved = alg_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("conv_bytes_per_launch")
-            except Exception:
-                traffic = None
-        if prec == "f32":
-            kern, peak, note = "fusg::conv_igemm_f32 (all tile instantiations)", PEAK_F32_MFMA_TFLOPS, \
-                "fp32 MFMA: 1 matrix FLOP per algorithmic FLOP"
+    def keep_settling(t_s):
+        # every rank must run the same number of steps (a step contains collectives): rank 0's clock decides
+        go = torch.tensor([1 if time.perf_counter() - t_s < args.settle_s else 0], dtype=torch.int32, device=coll_dev)
+        if world > 1:
+            dist.broadcast(go, src=0)
+        return bool(go.item())
+
+    def run_leg(prec, sampler=None):
+        """The full protocol for one precision: settle, W warm-up steps, K timed steps, then the roofline pass."""
+        ops.set_precision(prec)
+        if sampler:
+            sampler.start()
+        # Clock settle, before (and on top of) the W warm-up steps: the card's DVFS needs ~0.5 s of load to reach its
+        # steady operating point (a burst right after start-up reads 5-20 % slow or fast, DESIGN.md 4.3), and lazy
+        # initialisation (plan upload, stream creation, RCCL communicators) happens in the first step.
+        step()
+        torch.cuda.synchronize()
+        settle, t_s = 1, time.perf_counter()
+        while keep_settling(t_s):
+            step()
+            torch.cuda.synchronize()
+            settle += 1
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        pipe.finish()                                   # clear the range status before the timed region
+        del gather_ms[:]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        out_of_range = pipe.finish()                    # one 4-byte read for all K steps
+        # Roofline pass: the SAME K steps again with one HIP-event pair around every conv launch, recorded on
+        # the launch stream.  Kept out of the timed region above because ~460 event records per step cost
+        # ~10 % of wall time; kernel durations themselves are unaffected (rocprofv3 agrees, profiles/).
+        # The branches of the pass are serialised for this leg (FUSG_STREAMS=0): kernels that share the GPU with
+        # another stream's kernels would each read longer than they are.
+        roofline = None
+        if not args.no_prof:
+            streams_env = os.environ.get("FUSG_STREAMS")
+            os.environ["FUSG_STREAMS"] = "0"
+            step()
+            barrier()
+            ops.prof_reset()
+            ops.prof_enable(True)
+            for _ in range(args.steps):
+                step()
+            barrier()
+            ops.prof_enable(False)
+            if streams_env is None:
+                del os.environ["FUSG_STREAMS"]
+            else:
+                os.environ["FUSG_STREAMS"] = streams_env
+            conv_ms, conv_launches, launched_flops = ops.prof_read(0)
+            alg_flops = gflop_crop * 1e9 * args.batch * args.steps          # this rank's conv work in the timed region
+            achieved = alg_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            executed = launched_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            traffic, tsrc = None, None
+            tpath = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
+            if prec == "f16x3" and not args.inpaint and args.res == 256 and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("conv_bytes_per_launch")
+                    tsrc = "NOT measured in this run (PMC counters need their own rocprofv3 pass): %s, collected %s" % (
+                        "profiles/hbm_traffic_latest.json", tj.get("collected", "in an earlier run"))
+                except (OSError, ValueError):
+                    traffic = None
+            if prec == "f32":
+                kern, peak, note = "fusg::conv_igemm_f32 (all tile instantiations)", PEAK_F32_MFMA_TFLOPS, \
+                    "fp32 MFMA: 1 matrix FLOP per algorithmic FLOP"
+            else:
+                kern, peak, note = "fusg::conv_halo_h3 + conv_tapunit_h3 + conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
+                    ("split-fp16: every fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh'); peak = dense "
+                     "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
+            roofline = {"bound": "mfma", "kernel": kern,
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4),
+                        "achieved_executed": round(executed, 2), "frac_executed": round(executed / peak, 4),
+                        "traffic": traffic, "traffic_source": tsrc, "note": note,
+                        "executed_note": "FLOPs as launched (2*M*Cout*K_pad per launch): the ICN decoder's phase form does 2.8x "
+                                         "fewer MACs than the reference's 25-tap form that `achieved` prices",
+                        "measured": "second pass of the same K steps, branches serialised on one stream, one HIP-event pair per launch",
+                        "launches_per_step": conv_launches // max(1, args.steps),
+                        "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
+                        "conv_ms_per_step": round(conv_ms / args.steps, 3),
+                        "alg_gflop_per_launch": round(gflop_crop * args.batch * args.steps / max(1, conv_launches), 3)}
+        power = sampler.stop() if sampler else None
+        tstat = torch.tensor([dt, -dt, 1.0 if out_of_range else 0.0], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(tstat, op=dist.ReduceOp.MAX)
+        dt_max, dt_min, bad = float(tstat[0]), -float(tstat[1]), bool(tstat[2] > 0)
+        leg = {"value": round(n_total * args.steps / dt_max, 3), "unit": "crops/s",
+               "ms_per_step": round(dt_max / args.steps * 1e3, 3), "dtype": DTYPE[prec], "roofline": roofline,
+               "settle_steps": settle, "range_status_raised": bad}
+        if world > 1:
+            leg["per_rank_crops_per_s"] = {"min": round(args.batch * args.steps / dt_max, 2),
+                                           "max": round(args.batch * args.steps / dt_min, 2)}
+            leg["gather_enqueue_ms_per_step"] = round(sum(gather_ms) / max(1, len(gather_ms)), 3)
+        if power is not None:
+            leg["power"] = power
+        return leg
+
+    legs_wanted = ["f16x3", "f32"] if args.precision == "both" else [args.precision]
+    sampler = None
+    if rank == 0 and world == 1:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = None
+        if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        sampler = PowerSampler(bdf)
+    legs = {}
+    for i, prec in enumerate(legs_wanted):
+        legs[prec] = run_leg(prec, sampler if i == 0 else None)
+    head = legs_wanted[0]
+    if legs[head]["range_status_raised"]:
+        # cannot happen with the synthetic inputs; if it does, the f16x3 figure is not a valid measurement
+        if "f32" in legs and head != "f32":
+            head = "f32"
         else:
-            kern, peak, note = "fusg::conv_halo_h3 + fusg::conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
-                ("split-fp16: every algorithmic fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh); peak = dense "
-                 "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
-        roofline = {"bound": "mfma", "kernel": kern,
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "note": note,
-                    "measured": "second pass of the same K steps, branches serialised on one stream, one HIP-event pair per launch",
-                    "launches_per_step": conv_launches // max(1, args.steps),
-                    "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
-                    "conv_ms_per_step": round(conv_ms / args.steps, 3),
-                    "alg_gflop_per_launch": round(gflop_crop * args.batch * args.steps / max(1, conv_launches), 3)}
+            raise SystemExit("bench.py: the f16x3 range status was raised during the timed steps - leg invalid")
+    ops.set_precision(head)
 
     extra = {}
     if rank == 0 and world == 1 and not args.no_clip and not args.inpaint:
@@ -270,58 +425,45 @@ def main():
         from future_urban_scene_generation_amd.pipeline import synth_clip
         V, F = 8, 6
         clip = synth_clip(V, F, args.res, dev)
-        pipe.run_clip(clip)
+        pipe.run_clip(clip, check="async")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
-            pipe.run_clip(clip)
-        torch.cuda.synchronize()
+            pipe.run_clip(clip, check="async")
+        bad = pipe.finish()
         cdt = (time.perf_counter() - t1) / 3
         extra["clip_mode"] = {"vehicles": V, "frames": F, "ms_per_pass": round(cdt * 1e3, 3),
-                              "vehicle_clips_per_s": round(V / cdt, 2), "frames_per_s": round(V * F / cdt, 1)}
+                              "vehicle_clips_per_s": round(V / cdt, 2), "frames_per_s": round(V * F / cdt, 1),
+                              "range_status_raised": bool(bad)}
         del clip
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-        from future_urban_scene_generation_amd.pipeline import load_schema
-        from future_urban_scene_generation_amd.synth import synth_state_dict
-        ns = max(1, min(args.cpu_sample, args.batch))
-        sds = {n: synth_state_dict(n, load_schema(n), 0)
-               for n in (("hg", "icn", "vunet") + (("edge", "inpaint") if args.inpaint else ()))}
-        cpu_batch = {k: v[:ns].cpu() for k, v in batch.items()}
-        oracle.crop_pass(sds, {k: v[:1] for k, v in cpu_batch.items()}, args.inpaint)        # warm-up
-        torch.manual_seed(77)
-        t1 = time.perf_counter()
-        ref = oracle.crop_pass(sds, cpu_batch, args.inpaint)
-        cpu_dt = time.perf_counter() - t1
-        cpu_baseline = {"value": round(ns / cpu_dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": f"{ns} crops of the same workload (batch {ns}), 1 timed pass after warm-up"}
-        # quality of the GPU path on the very same sample and noise seed
-        torch.manual_seed(77)
-        got = pipe.run({k: v[:ns] for k, v in batch.items()})
-        import numpy as np
-        extra["ssim_vs_cpu_ref"] = round(min(oracle.ssim(got["icn_u8"].cpu().numpy(), ref["icn_u8"]),
-                                             oracle.ssim(got["vunet_u8"].cpu().numpy(), ref["vunet_u8"])), 6)
-        extra["kp_idx_exact"] = bool(np.array_equal(got["kp_idx"].cpu().numpy(), ref["kp_idx"]))
+        cpu_baseline, quality = cpu_baseline_leg(args, batch, pipe, torch)
+        extra.update(quality)
 
     if rank == 0:
-        line = {"metric": "synthesised vehicle crops/sec @%dx%d" % (args.res, args.res), "value": round(crops_per_s, 3), "unit": "crops/s",
+        h = legs[head]
+        line = {"metric": "synthesised vehicle crops/sec @%dx%d" % (args.res, args.res), "value": h["value"], "unit": "crops/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.vehicles else "weak",
-                "vs_baseline": None,
-                "dtype": "f32" if prec == "f32" else "f32 operands as 3x f16 split products, f32 accumulate (fp32-class accuracy)",
-                "data": "synthetic",
+                "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.vehicles else "weak",
+                "vs_baseline": None, "dtype": h["dtype"], "data": "synthetic",
                 "config": {"workload": ("configs[2]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet + edgeconnect"
                                         if args.inpaint else
                                         "configs[1]: batch=%d %dx%d crops/GPU, hourglass->warp_learn(ICN)->vunet first-frame") % (args.batch, args.res, args.res)
                                        + (" | strong scaling: %d vehicles of one frame sharded over the ranks (configs[3])" % args.vehicles if args.vehicles else ""),
-                           "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint), "precision": prec,
+                           "batch_per_gpu": args.batch, "res": args.res, "inpaint": bool(args.inpaint), "precision": head,
                            "gflop_per_crop": round(gflop_crop, 2), "sharding": "vehicles over ranks, gather of uint8 crops to rank 0"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline}
+                "roofline": h["roofline"], "cpu_baseline": cpu_baseline,
+                "precision_legs": {k: {kk: vv for kk, vv in v.items() if kk != "power"} for k, v in legs.items()}}
+        if world > 1:
+            line["rccl_ranks"] = dist.get_world_size()
+            line["dist_backend"] = dist.get_backend()
+            line["per_rank_crops_per_s"] = h.get("per_rank_crops_per_s")
+            line["gather_enqueue_ms_per_step"] = h.get("gather_enqueue_ms_per_step")
         line.update(extra)
-        if power is not None:
-            line["power"] = power
-        line["settle_steps"] = settle
+        if h.get("power") is not None:
+            line["power"] = h["power"]
+        line["settle_steps"] = h["settle_steps"]
         line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch"
         print(json.dumps(line), flush=True)
     if world > 1:

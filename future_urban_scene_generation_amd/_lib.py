@@ -43,7 +43,8 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("kh", C.c_int32), ("kw", C.c_int32), ("dil", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
                 ("wfrag_order", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
                 ("tile_list", C.c_void_p), ("tile_count", C.c_int32), ("q_oy", C.c_int32), ("q_ox", C.c_int32),
-                ("stats_slots", C.c_int32)]
+                ("stats_slots", C.c_int32),
+                ("wscale", C.c_void_p), ("status", C.c_void_p)]
 
 
 # enums (include/fusg.h)

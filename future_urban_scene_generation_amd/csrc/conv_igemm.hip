@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK p, int nph
         if (n < p.Cout) {
             PixOff co;
             chan_offsets(p, n, co);
-            epi_store(p, po, co, p.bias[n], s[c]);
+            epi_store(p, po, co, p.bias[n], p.wscale ? p.wscale[n] : 1.f, s[c]);
         }
     }
 }
@@ -106,7 +106,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     FUSG_CHECK(d->bias && d->ktab, "conv2d: bias/ktab missing");
     FUSG_CHECK(d->precision == FUSG_PREC_F32 || d->precision == FUSG_PREC_F16X3, "conv2d: precision %d", d->precision);
     if (d->precision == FUSG_PREC_F32) FUSG_CHECK(d->wpack, "conv2d: wpack missing");
-    else FUSG_CHECK(d->wpack_h && (((uintptr_t)d->wpack_h) & 15) == 0, "conv2d: F16X3 needs a 16B-aligned wpack_h");
+    else FUSG_CHECK(d->wpack_h && (((uintptr_t)d->wpack_h) & 15) == 0 && d->wscale && (((uintptr_t)d->wscale) & 15) == 0 && d->status,
+                    "conv2d: F16X3 needs 16B-aligned wpack_h and wscale, and a status word");
     FUSG_CHECK((((uintptr_t)d->wpack) & 15) == 0 && (((uintptr_t)d->ktab) & 7) == 0, "conv2d: wpack/ktab misaligned");
     FUSG_CHECK(d->k_pad > 0 && d->k_pad % BK == 0, "conv2d: k_pad %d not a positive multiple of %d", d->k_pad, BK);
     FUSG_CHECK(d->cout > 0 && d->cout_pad % 32 == 0 && d->cout <= d->cout_pad, "conv2d: bad cout %d / cout_pad %d", d->cout, d->cout_pad);
@@ -191,6 +192,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     k.zeros = zero_line();
     if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
     k.wpack_h = (const _Float16*)d->wpack_h;
+    if (d->precision == FUSG_PREC_F16X3) { k.wscale = d->wscale; k.status = d->status; }
     k.H = (int)x0.h; k.W = (int)x0.w; k.ups = d->upsample; k.Hv = k.H << k.ups; k.Wv = k.W << k.ups;
     k.Cs0 = (int)x0.sw; k.Cs1 = has1 ? (int)d->src1.sw : (int)x0.sw; k.C0 = d->c0k;
     k.K_pad = d->k_pad; k.nk = d->k_pad / BK; k.Cout = d->cout; k.Cout_pad = d->cout_pad;

@@ -52,6 +52,10 @@ struct ConvK {
     float* stats;            // optional fused norm statistics: [B][stats_slots][Cout][2] = (mean, M2) per 32-pixel slot
     int stats_slots;         // slots per image = qh*qw/32
     int qy0, qx0;            // origin of the computed Ho x Wo window in q-space (generic kernels; 0 for the halo kernel)
+    const float* wscale;     // f16x3 path: per-output-channel 1/s of the power-of-two weight scale s applied at pack
+                             // time (pack.split_f16x3); the epilogue computes acc * wscale[n] + bias[n].  NULL = 1.
+    int* status;             // f16x3 path: set to 1 by any workgroup that stages an operand with |x| >= 2^15 (outside
+                             // the range the fp16 split represents); the caller re-runs the pass in exact fp32
     const float* zeros;      // 256 B of zeros in device memory: where the gather of a zero-padded pixel reads.  It
                              // comes in through the kernel arguments so that the selected pointer stays a GLOBAL
                              // one (a select against the address of a __device__ variable degrades the load to
@@ -103,8 +107,8 @@ __device__ __forceinline__ void chan_offsets(const ConvK& p, int n, PixOff& o) {
         o.d = (long)n * p.dsc; o.r0 = (long)n * p.r0c; o.r1 = (long)n * p.r1c;
     }
 }
-__device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, const PixOff& co, float bias, float v) {
-    v = act_apply(v + bias, p.act);
+__device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, const PixOff& co, float bias, float wsc, float v) {
+    v = act_apply(fmaf(v, wsc, bias), p.act);
     if (p.res0) v += p.res0[po.r0 + co.r0];
     if (p.res1) v += p.res1[po.r1 + co.r1];
     p.dst[po.d + co.d] = v;
@@ -137,10 +141,14 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
     const int c4 = lane % Q;
     const int n = ncol_base + c4 * 4;
     const bool nvalid = n < p.Cout;
-    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f}, wsc = {1.f, 1.f, 1.f, 1.f};
     PixOff co;
     co.d = co.r0 = co.r1 = 0;
-    if (nvalid) { bs = *(const f32x4*)(p.bias + n); chan_offsets(p, n, co); }
+    if (nvalid) {
+        bs = *(const f32x4*)(p.bias + n);
+        if (p.wscale) wsc = *(const f32x4*)(p.wscale + n);
+        chan_offsets(p, n, co);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         f32x4 vals[ITER];
@@ -153,7 +161,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
             full = full && ok;
             f32x4 v = *(const f32x4*)(wlds + row * PITCH + c4 * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bs[c], p.act);
+            for (int c = 0; c < 4; ++c) v[c] = act_apply(fmaf(v[c], wsc[c], bs[c]), p.act);
             vals[it] = v;
             if (nvalid && ok) {
                 if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
@@ -407,13 +415,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
         return;
     }
     PixOff co[TN];
-    float bias[TN];
+    float bias[TN], wsc[TN];
     bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
         nok[j] = n < p.Cout;
         bias[j] = p.bias[n];
+        wsc[j] = p.wscale ? p.wscale[n] : 1.f;
         chan_offsets(p, n, co[j]);
     }
 #pragma unroll
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
             if (pix_offsets(p, phase, m, po)) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+                    if (nok[j]) epi_store(p, po, co[j], bias[j], wsc[j], acc[i][j][r]);
             }
         }
 }

@@ -1,12 +1,24 @@
 // Split-precision variant of the fused implicit-GEMM convolution (gfx950): fp32 operands are split
-// on the fly into fp16 (hi, lo) pairs (hi = top 11 significant bits, lo = the fp32 residual rounded
-// to fp16) and multiplied on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate) as
-//     a*w ~= ah*wh + ah*wl + al*wh        (al*wl ~ 2^-22 |a w| is dropped)
-// fp16 x fp16 products are exact in fp32 (11+11 significant bits) and all three terms go into the
-// same fp32 accumulator.  gfx950's fp16 MFMA keeps fp16 subnormals (verified on hardware: the
-// parity suite, including the ill-conditioned ICN fixture, passes bit-for-bit-class with unscaled
-// residuals), so lo needs no scaling: |lo| < 2^-11 |a| simply degrades gracefully to an absolute
-// 2^-25 floor.  Cost: 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less matrix-pipe time.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
+// on the fly into fp16 pairs and multiplied on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32
+// accumulate) as
+//     a*w ~= ah*wh + ah*wl + al'*(wh * 2^-11)        (the al*wl term, <= 2^-22 |a w|, is dropped)
+//   ah  = a rounded toward zero to fp16 (11 significant bits)
+//   al' = (a - ah) * 2^11 rounded to fp16: the residual is SCALED into the range of ah, so it keeps 11
+//         significant bits for every |a| in fp16's normal range [2^-14, 2^15) instead of sinking into
+//         fp16 subnormals (round 1 stored it unscaled: an absolute 2^-25 floor, i.e. fp32-class only for
+//         |a| ~ 1)
+//   wh, wl = the weights times a per-output-channel power of two s_n that puts the largest |w| of the
+//         channel in [2^13, 2^14) (pack.split_f16x3), wl = w s_n - wh unscaled (its floor, 2^-24, is
+//         2^-37 of the channel's largest weight); the epilogue multiplies by 1/s_n (exact).
+// The third term's B operand wh * 2^-11 is formed in registers (v_pk_mul_f16, exact unless a weight is
+// 2^-17 of its channel's largest, where the term is negligible).  fp16 x fp16 products are exact in
+// fp32 and all three terms go into the same fp32 accumulator.  CPU emulation over operand scales
+// 1e-4 .. 1e4 (tools/emu_split.py): 0.3-0.7x the error of an fp32 fmaf chain at K = 2304.
+// Range: |a| >= 2^15 cannot be represented (al' would overflow).  Nothing is clamped: every staged
+// operand feeds a running max |a|, and a workgroup that saw |a| >= 2^15 (or an infinity) raises
+// ConvK::status, on which the caller re-runs the pass in exact fp32 (ops.py).  NaNs propagate.
+// Cost: 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less matrix-pipe time; 3 VALU ops per
+// staged element for the split.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
 // LDS: four fp16 tiles per buffer, [row][32 halves] = 64-byte rows whose four 16-byte chunks are
 // XOR-swizzled with (row >> 2) & 3: conflict-free ds_read_b128 operand fetches without padding, so a
 // 128x128 workgroup needs exactly 64 KiB and two workgroups share a CU's 160 KiB.
@@ -24,25 +36,41 @@ constexpr int LDH = 32;                 // LDS row pitch in halves (64 B, XOR-sw
 
 typedef __fp16 h2 __attribute__((ext_vector_type(2)));     // type returned by cvt_pkrtz
 
-// Split 4 fp32 values into fp16 (hi, lo*2^11).  `lo_bound` is -65504 (plain clamp) or 0 (the clamp
-// doubles as the fused ReLU).  hi keeps the top 10 mantissa bits (bit mask: exactly representable
-// in fp16 for normal-range values), the residual is exact in fp32, and both halves are packed with
-// v_cvt_pkrtz_f16_f32.  ~4.5 VALU ops per element.
-__device__ __forceinline__ void split4(const f32x4 v, float lo_bound, h4& hi, h4& lo) {
-    float hf[4], lf[4];
+constexpr float F16X3_LIMIT = 32768.f;   // |a| >= 2^15: outside the split's range -> ConvK::status
+
+// Split 4 fp32 values into fp16 (hi, lo') = (RTZ(a), RTN((a - hi) * 2^11)) after v = max(v, floor)
+// (`floor` = 0 for a fused ReLU, -inf otherwise) and fold |v| into the running maximum `amax`.
+// hi: v_cvt_pkrtz_f16_f32 (0.5 op / element); lo': v_mul (a * 2^11) + v_fma_mix{lo,hi}_f16, which reads
+// hi straight from its fp16 half, computes hi * -2^11 + a * 2^11 exactly in fp32 and rounds once to fp16
+// (hipcc has no pattern for it: inline asm); amax: v_max3_f32 with |.| source modifiers.  3 VALU ops per
+// element + 1 for the floor.
+__device__ __forceinline__ void split4(f32x4 v, float floor, h4& hi, h4& lo, float& amax) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float a = __builtin_amdgcn_fmed3f(v[c], lo_bound, 65504.f);
-        hf[c] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
-        lf[c] = a - hf[c];
-    }
-    const h2 h01 = __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]), h23 = __builtin_amdgcn_cvt_pkrtz(hf[2], hf[3]);
-    const h2 l01 = __builtin_amdgcn_cvt_pkrtz(lf[0], lf[1]), l23 = __builtin_amdgcn_cvt_pkrtz(lf[2], lf[3]);
+    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], floor);
+    const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const unsigned p01 = __builtin_bit_cast(unsigned, h01), p23 = __builtin_bit_cast(unsigned, h23);
+    const float m2048 = -2048.f;
+    const float s0 = v[0] * 2048.f, s1 = v[1] * 2048.f, s2 = v[2] * 2048.f, s3 = v[3] * 2048.f;
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(p01), "s"(m2048), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(p01), "s"(m2048), "v"(s1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(p23), "s"(m2048), "v"(s2));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(p23), "s"(m2048), "v"(s3));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 hp = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-    const u32x2 lp = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    const u32x2 hp = {p01, p23}, lp = {l01, l23};
     hi = __builtin_bit_cast(h4, hp);
     lo = __builtin_bit_cast(h4, lp);
+}
+
+// wh * 2^-11: the B operand of the al' term (v_pk_mul_f16 x 4)
+__device__ __forceinline__ h8 scale_m11(const h8 x) { return x * (_Float16)0x1p-11f; }
+
+// raise ConvK::status when this lane staged an operand outside the split's range (plain store: every writer
+// stores the same value)
+__device__ __forceinline__ void report_range(const ConvK& p, float amax) {
+    if (amax >= F16X3_LIMIT && p.status) *p.status = 1;
 }
 
 // Out-of-image lanes of the pre-op kinds with f(0) = 0 read ConvK::zeros instead of being masked after the load.
@@ -126,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         bpiece[j] = q & 3;
     }
 
-    const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
+    const float vfloor = (PK != PK_ELU && p.pre_relu) ? 0.f : -__builtin_inff();
+    float amax = 0.f;
     struct Stage {
         f32x4 a[AP];
         u32x4 bh[BPL], bl[BPL];
@@ -229,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                 for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
             }
             h4 hi, lo;
-            split4(v, lo_bound, hi, lo);
+            split4(v, vfloor, hi, lo, amax);
             *(h4*)(ah + 32 * i * LDH) = hi;
             *(h4*)(al + 32 * i * LDH) = lo;
         }
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         const _Float16* blb = Bl + buf * BN * LDH + b_off;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            h8 ah[TM], al[TM], bh[TN], bl[TN];
+            h8 ah[TM], al[TM], bh[TN], bl[TN], bs[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *(const h8*)(ahb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
@@ -275,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             for (int i = 0; i < TN; ++i) {
                 bh[i] = *(const h8*)(bhb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
                 bl[i] = *(const h8*)(blb + i * 32 * LDH + (((2 * c + hh) ^ rsw) << 3));
+                bs[i] = scale_m11(bh[i]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bs[j], acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -327,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         if (s < s_end) compute(0);             // odd count: the last step sits in buffer 0
     }
 
+    report_range(p, amax);
     // ---------------------------------------------------------------- epilogue
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
     const int mrow0 = mt * BM + wm * TM * 32 + 4 * (lane >> 5);
@@ -359,13 +390,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         return;
     }
     PixOff co[TN];
-    float bias[TN];
+    float bias[TN], wsc[TN];
     bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
         nok[j] = n < p.Cout;
         bias[j] = p.bias[n];
+        wsc[j] = p.wscale ? p.wscale[n] : 1.f;
         chan_offsets(p, n, co[j]);
     }
 #pragma unroll
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
             if (pix_offsets(p, phase, m, po)) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+                    if (nok[j]) epi_store(p, po, co[j], bias[j], wsc[j], acc[i][j][r]);
             }
         }
 }

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
     // this wave's weight fragments: tiles (nt*BN/32 + wn*TN + j), j < TN
     const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 4 * 64 + lane) * 8;
     const long wstep = (long)hk.nt32 * 4 * 64 * 8;            // halves per (tap, chunk) slab
-    const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
+    const float vfloor = (PK != PK_ELU && p.pre_relu) ? 0.f : -__builtin_inff();
+    float amax = 0.f;
     const int nchq = p.C0 / CH;                                 // chunks per quadrant (quadrant form)
     const int nch0 = hk.s2d ? 4 * nchq : p.C0 / CH, nch = nch0 + hk.c1k / CH;
     const int nch32 = (p.C0 + hk.c1k) >> 5;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
             h4 hi, lo;
-            split4(v, lo_bound, hi, lo);
+            split4(v, vfloor, hi, lo, amax);
             if ((hexist >> j) & 1u) {
                 *(h4*)(Ah + hoff[j]) = hi;
                 *(h4*)(Al + hoff[j]) = lo;
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
                 ah[i] = *(const h8*)(Ah + abase[i] + toff + c * 16);
                 al[i] = *(const h8*)(Al + abase[i] + toff + c * 16);
             }
+            h8 bs[TN];                                             // wh * 2^-11: B operand of the al' term
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bs[j] = scale_m11(F.f[j][c][0]);
             // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one
             // accumulator stalls the issue: measured SQ_WAIT_INST_ANY 50 % with the accumulator-major order)
 #pragma unroll
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i], F.f[j][c][term == 1 ? 1 : 0],
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i],
+                                                                           term == 0 ? F.f[j][c][0] : term == 1 ? F.f[j][c][1] : bs[j],
                                                                            acc[i][j], 0, 0, 0);
         }
     };
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         if (cg >= nch) break;
     }
 
+    report_range(p, amax);
     // ---------------------------------------------------------------- epilogue
     const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
     if (p.vec_epi) {
@@ -285,13 +291,14 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         return;
     }
     PixOff co[TN];
-    float bias[TN];
+    float bias[TN], wsc[TN];
     bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
         nok[j] = n < p.Cout;
         bias[j] = p.bias[n];
+        wsc[j] = p.wscale ? p.wscale[n] : 1.f;
         chan_offsets(p, n, co[j]);
     }
 #pragma unroll
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+                if (nok[j]) epi_store(p, po, co[j], bias[j], wsc[j], acc[i][j][r]);
         }
 }
 

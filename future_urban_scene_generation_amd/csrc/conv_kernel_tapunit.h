@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
         constexpr int NI = 8;
         const int ipp = hk.CP >> 2;                                // items per pixel
         const int nitems = hk.HH * hk.HW * ipp;                    // <= 256 * NI (checked on the host)
-        const float lo_bound = (PK != PK_ELU && p.pre_relu) ? 0.f : -65504.f;
+        const float vfloor = (PK != PK_ELU && p.pre_relu) ? 0.f : -__builtin_inff();
+        float amax = 0.f;
         const long img_pix0 = (long)b * p.H * p.W;
         f32x4 hreg[NI];
         int hoff[NI];
@@ -106,10 +107,11 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
             h4 hi, lo;
-            split4(v, lo_bound, hi, lo);
+            split4(v, vfloor, hi, lo, amax);
             *(h4*)(Ah + hoff[j]) = hi;
             *(h4*)(Al + hoff[j]) = lo;
         }
+        report_range(p, amax);
     }
 
     // this wave's weight fragments: column tiles (nt*BN/32 + wn*TN + j), j < TN
@@ -173,13 +175,17 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
                 al[i] = h8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
             }
         }
+        h8 bs[TN];                                                 // wh * 2^-11: B operand of the al' term
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bs[j] = scale_m11(F.f[j][0]);
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i], F.f[j][term == 1 ? 1 : 0],
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i],
+                                                                       term == 0 ? F.f[j][0] : term == 1 ? F.f[j][1] : bs[j],
                                                                        acc[i][j], 0, 0, 0);
     };
     int step = 0;
@@ -207,13 +213,14 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
         return;
     }
     PixOff co[TN];
-    float bias[TN];
+    float bias[TN], wsc[TN];
     bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
         nok[j] = n < p.Cout;
         bias[j] = p.bias[n];
+        wsc[j] = p.wscale ? p.wscale[n] : 1.f;
         chan_offsets(p, n, co[j]);
     }
 #pragma unroll
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
             pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                if (nok[j]) epi_store(p, po, co[j], bias[j], acc[i][j][r]);
+                if (nok[j]) epi_store(p, po, co[j], bias[j], wsc[j], acc[i][j][r]);
         }
 }
 

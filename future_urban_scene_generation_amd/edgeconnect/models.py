@@ -14,7 +14,6 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
 from .networks import EdgeGenerator, InpaintGenerator
 
 
@@ -29,14 +28,16 @@ class BaseModel(nn.Module):
         self.dis_weights_path = os.path.join(path, name + "_dis.pth")
 
     def load(self):
-        if os.path.exists(self.gen_weights_path):
-            print("Loading %s generator..." % self.name)
-            data = torch.load(self.gen_weights_path, map_location=lambda storage, loc: storage)
-            self.generator.load_state_dict(data["generator"])
-            self.iteration = data["iteration"]
+        """Reads `<PATH>/<name>_gen.pth` = {'iteration': int, 'generator': state_dict} when it exists (the
+        reference's checkpoint contract, edgeconnect/models.py:25-30); a missing file leaves the initial weights."""
+        if not os.path.exists(self.gen_weights_path):
+            return
+        ckpt = torch.load(self.gen_weights_path, map_location="cpu")
+        self.generator.load_state_dict(ckpt["generator"])
+        self.iteration = ckpt["iteration"]
 
     def save(self):
-        print("\nsaving %s...\n" % self.name)
+        """Writes the same file `load` reads (edgeconnect/models.py:38-48, generator half)."""
         torch.save({"iteration": self.iteration, "generator": self.generator.state_dict()}, self.gen_weights_path)
 
     def process(self, *a, **k):
@@ -51,9 +52,7 @@ class EdgeModel(BaseModel):
         self.add_module("generator", EdgeGenerator(use_spectral_norm=True))
 
     def forward(self, images, edges, masks):
-        g = self.generator
-        g._ensure(images)
-        return g._run(ops.ec_inputs(images, edges, masks, 0))     # cat(img*(1-m)+m, edge*(1-m), m)
+        return self.generator.run_model(images, edges, masks, 0)   # cat(img*(1-m)+m, edge*(1-m), m) -> generator
 
 
 class InpaintingModel(BaseModel):
@@ -62,6 +61,4 @@ class InpaintingModel(BaseModel):
         self.add_module("generator", InpaintGenerator())
 
     def forward(self, images, edges, masks):
-        g = self.generator
-        g._ensure(images)
-        return g._run(ops.ec_inputs(images, edges, masks, 1))     # cat(img*(1-m)+m, edge)
+        return self.generator.run_model(images, edges, masks, 1)   # cat(img*(1-m)+m, edge) -> generator

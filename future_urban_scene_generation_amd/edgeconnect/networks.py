@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, pack
-from ..nn_base import ConvP, FusedNet, SNConvP
+from ..nn_base import ConvP, FusedNet, SNConvP, entry_point
 
 
 def _holder(cin, cout, k, spectral: bool, bias: bool = True, transposed: bool = False):
@@ -109,6 +109,14 @@ class _Generator(FusedNet):
         c, st = ops.conv_in(P["up2_ph"] if halo_ok(c) else P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         return ops.conv_rowsplit(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act)
 
+    @entry_point
+    def run_model(self, images: torch.Tensor, edges: torch.Tensor, masks: torch.Tensor, mode: int) -> torch.Tensor:
+        """EdgeModel.forward (mode 0) / InpaintingModel.forward (mode 1): input assembly + generator
+        (edgeconnect/models.py:130-135, 236-240)."""
+        self._ensure(images)
+        return self._run(ops.ec_inputs(images, edges, masks, mode))
+
+    @entry_point
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._ensure(x)
         if x.dim() != 4 or x.shape[1] != self.cin or x.shape[2] % 4 or x.shape[3] % 4:

@@ -9,6 +9,7 @@ parameters may have changed (``load_state_dict``, ``.to()``, ``.float()`` ..., o
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Optional
 
@@ -92,6 +93,57 @@ class SNConvP(nn.Module):
         self.register_buffer("weight_v", v)
 
 
+def entry_point(fn):
+    """Decorator of the reference-facing entry points (forward, forward_enc_up, ...).
+
+    Device guard: the reference's torch modules run on whatever device their tensors live on; libfusg launches on
+    the CURRENT HIP device and ops.stream_ptr() returns the current device's stream, so the call is executed with
+    the module's device made current (a model on 'cuda:1' works without torch.cuda.set_device(1)).
+
+    Range guard: with the split-fp16 contraction (ops.PRECISION == "f16x3") a launch that meets an operand outside
+    the split's range raises a device-side status word instead of saturating; this wrapper reads the word after the
+    call (one 4-byte read = one stream synchronisation, which the reference's callers do anyway when they `.cpu()`
+    the result) and, when it is set, repeats the call in exact fp32 with the CPU generators rewound and list
+    arguments (the `skips` a VUnet decoder consumes) restored - the caller only ever sees a result every operand of
+    which was represented.  Nested entry points (Vunet_fix_res.forward -> forward_*) are checked once, by the
+    outermost one; `ops.defer_range_check()` (VehiclePipeline) postpones the check to the caller."""
+
+    def guarded(self, dev, args, kwargs):
+        from . import ops
+        if ops.PRECISION != "f16x3" or ops._GUARD["depth"] > 0 or ops._GUARD["deferred"] > 0:
+            return fn(self, *args, **kwargs)
+        snap = self._rng_snapshot()
+        lists = [(a, list(a)) for a in args if isinstance(a, list)]
+        ops._GUARD["depth"] += 1
+        try:
+            out = fn(self, *args, **kwargs)
+        finally:
+            ops._GUARD["depth"] -= 1
+        if not ops.range_exceeded(dev):
+            return out
+        self._rng_restore(snap)
+        for a, saved in lists:
+            a[:] = saved
+        ops._GUARD["depth"] += 1
+        try:
+            with ops.precision("f32"):
+                return fn(self, *args, **kwargs)
+        finally:
+            ops._GUARD["depth"] -= 1
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = self._device()
+        if dev.type != "cuda":
+            return fn(self, *args, **kwargs)                      # raises the "HIP device only" error inside
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return guarded(self, dev, args, kwargs)
+        return guarded(self, dev, args, kwargs)
+
+    return wrapper
+
+
 class FusedNet(nn.Module):
     """Base of the four drop-in networks: plan cache + invalidation + device checks."""
 
@@ -115,6 +167,13 @@ class FusedNet(nn.Module):
         r = super()._apply(fn, *args, **kwargs)
         self.refresh()
         return r
+
+    # -- host RNG state an entry point consumes (only the VUnet's samplers draw noise) --------
+    def _rng_snapshot(self):
+        return None
+
+    def _rng_restore(self, snap) -> None:
+        pass
 
     # -- helpers ----------------------------------------------------------------------------
     def _device(self) -> torch.device:

@@ -40,6 +40,66 @@ def set_precision(name: str) -> None:
     PRECISION = name
 
 
+class precision:
+    """`with ops.precision("f32"):` - temporary override of the process-wide contraction arithmetic."""
+
+    def __init__(self, name: str):
+        if name not in _PREC:
+            raise ValueError(f"precision must be one of {list(_PREC)}")
+        self.name = name
+
+    def __enter__(self):
+        global PRECISION
+        self.prev, PRECISION = PRECISION, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
+# ---- range guard of the split-fp16 contraction --------------------------------------------------------------
+# An f16x3 launch that stages an operand with |x| >= 2^15 (or a non-finite one) cannot represent it and raises a
+# device-side status word instead of clamping (include/fusg.h, fusg_precision).  The word is caller-owned: one int32
+# per device, here.  The module entry points (nn_base.range_guarded) and VehiclePipeline.run read it after their
+# launches and redo the call in exact fp32 when it is set, so a result computed from a saturated operand never
+# reaches the caller.
+_STATUS = {}
+_GUARD = {"depth": 0, "deferred": 0}
+
+
+def status_word(device) -> torch.Tensor:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    w = _STATUS.get(key)
+    if w is None:
+        w = _STATUS[key] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", key))
+    return w
+
+
+def range_exceeded(device, clear: bool = True) -> bool:
+    """Has any f16x3 launch on `device` since the last clear seen an operand outside the split's range?
+    Synchronises the current stream (a 4-byte read)."""
+    w = status_word(device)
+    hit = bool(w[0].item())
+    if hit and clear:
+        w.zero_()
+    return hit
+
+
+class defer_range_check:
+    """Inside this context the module entry points do not read the status word (no host synchronisation per
+    network): the caller checks once, after all its launches (VehiclePipeline.run / finish)."""
+
+    def __enter__(self):
+        _GUARD["deferred"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _GUARD["deferred"] -= 1
+        return False
+
+
 def _require_gpu(t: torch.Tensor, what: str = "input") -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what} is on {t.device}: the MI355X-native modules run on a HIP device only "
@@ -220,6 +280,8 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     d.tile, d.ksplit = int(tile), int(ksplit)
     d.precision = _PREC[precision or PRECISION]
     d.wpack_h = dev["wpack_h"].data_ptr()
+    d.wscale = dev["wscale"].data_ptr()
+    d.status = status_word(x0.device).data_ptr()
     if plan.nphase == 1:                      # dense kh x kw tap grid: lets the library pick the halo-tiled kernel
         d.kh, d.kw, d.dil = plan.kh, plan.kw, plan.dil
         d.pad_h, d.pad_w = plan.pad, (plan.pad if plan.pad_w < 0 else plan.pad_w)

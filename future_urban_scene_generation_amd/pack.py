@@ -56,8 +56,9 @@ class ConvPlan:
                         "ktab": self.ktab.to(device).contiguous()}
             if self.rowsplit is not None:
                 self.dev["rs_bias"] = self.rowsplit["bias"].to(device).contiguous()
-            wsplit = split_f16x3(self.wpack)
+            wsplit, wscale = split_f16x3(self.wpack)
             self.dev["wpack_h"] = wsplit.to(device).contiguous()
+            self.dev["wscale"] = wscale.to(device).contiguous()
             frag = frag_f16x3(wsplit, self) if self.nphase == 1 else None
             if frag is not None and self.s2d_ok():
                 frag = frag[s2d_tap_order(self.kh)].contiguous()       # slabs in (parity quadrant, local tap) order
@@ -97,13 +98,23 @@ class ConvPlan:
                 (wv + 2 * pw - self.dil * (self.kw - 1) - 1) // self.stride + 1)
 
 
-def split_f16x3(wpack: torch.Tensor) -> torch.Tensor:
-    """[nphase, cout_pad, k_pad] f32 -> [nphase, 2, cout_pad, k_pad] f16 = (hi, w - hi):
-    the weight half of the split-precision contraction (csrc/conv_kernel_h3.h)."""
-    w = wpack.clamp(-65504.0, 65504.0)
-    hi = w.to(torch.float16)
-    lo = (w - hi.to(torch.float32)).to(torch.float16)
-    return torch.stack([hi, lo], dim=1)
+def split_f16x3(wpack: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[nphase, cout_pad, k_pad] f32 -> ([nphase, 2, cout_pad, k_pad] f16 = (hi, lo) of w * s[n], 1 / s [cout_pad] f32):
+    the weight half of the split-precision contraction (csrc/conv_kernel_h3.h).  s[n] is the power of two that puts
+    the largest |w| of output channel n (over all phases) in [2^13, 2^14): hi = RTN(w s) then has 11 significant bits
+    for every weight down to 2^-27 of the channel's largest, lo = RTN(w s - hi) is stored unscaled (its absolute floor,
+    fp16's 2^-24, is 2^-37 of the largest weight) and hi * 2^-11 - formed in registers for the third product - stays
+    exact down to 2^-17 of it.  The scale is exact to undo: the conv epilogue multiplies the accumulator by 1 / s[n]."""
+    w = wpack.to(torch.float64)
+    rowmax = w.abs().amax(dim=(0, 2))
+    ok = torch.isfinite(rowmax) & (rowmax > 0)
+    _, e = torch.frexp(torch.where(ok, rowmax, torch.ones_like(rowmax)))       # rowmax = m * 2^e, m in [0.5, 1)
+    sh = torch.where(ok, 14 - e, torch.zeros_like(e)).clamp(-100, 100)
+    s = torch.pow(torch.tensor(2.0, dtype=torch.float64), sh.to(torch.float64))
+    ws = w * s[None, :, None]
+    hi = ws.to(torch.float32).to(torch.float16)
+    lo = (ws - hi.to(torch.float64)).to(torch.float32).to(torch.float16)
+    return torch.stack([hi, lo], dim=1), (1.0 / s).to(torch.float32)
 
 
 def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:

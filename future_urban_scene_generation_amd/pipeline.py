@@ -51,7 +51,9 @@ def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0)
 
 
 def load_schema(net: str):
-    with open(os.path.join(_REPO, "tests", "golden", f"schema_{net}.json")) as f:
+    """state_dict schema (key -> (shape, dtype)) of one of the five reference networks, as dumped from the
+    reference's own modules (tools/gen_golden.py); shipped inside the package (schemas/)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "schemas", f"schema_{net}.json")) as f:
         raw = json.load(f, object_pairs_hook=OrderedDict)
     return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
 
@@ -127,13 +129,53 @@ class VehiclePipeline:
             main.wait_stream(st)
         return out
 
-    @torch.no_grad()
-    def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
+    # Range guard of the split-fp16 contraction (ops.py): the networks' own per-call checks are deferred while a pass
+    # is being issued (they would synchronise the host once per network and undo the stream overlap); the pass is
+    # checked as a whole instead.  check="sync" (default): read the status word after the pass and, if an operand
+    # left the split's range, redo the pass in exact fp32 - the returned tensors are always valid.  check="async":
+    # return without synchronising (the caller keeps issuing passes); the status word is sticky, and `finish()`
+    # says whether any pass since the last call was affected - call it before consuming outputs.
+    def _guarded(self, fn, args, check: str, rng_state):
+        from . import ops
+        if ops.PRECISION != "f16x3" or check is None:
+            return fn(*args)
+        with ops.defer_range_check():
+            out = fn(*args)
+        if check == "async":
+            return out
+        with torch.cuda.device(self.device):
+            hit = ops.range_exceeded(self.device)
+        if not hit:
+            return out
+        if rng_state is not None:
+            torch.set_rng_state(rng_state)
+        with ops.defer_range_check(), ops.precision("f32"):
+            return fn(*args)
+
+    def finish(self) -> bool:
+        """Synchronise the device and report (and clear) the range status of the passes issued with check="async":
+        True = some pass staged an operand outside the split-fp16 range; its outputs must be recomputed
+        (`ops.precision("f32")`)."""
+        from . import ops
+        torch.cuda.synchronize(self.device)
+        if ops.PRECISION != "f16x3":
+            return False
+        with torch.cuda.device(self.device):
+            return ops.range_exceeded(self.device)
+
+    def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
+            check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
         """batch: 'hg_x' [B,3,R,R], 'icn_x' [B,21,R,R], 'vu_x' [B,6,R,R], 'vu_y' [B,3,R,R]
         (+ 'ec_img','ec_gray','ec_edge','ec_mask' with inpaint).  All device-resident.
         Returns 'kp_idx' int32 [B,12], 'icn_u8' / 'vunet_u8' uint8 [B,R,R,3] (+ 'inpaint_u8').
         vehicle_seeds: one VUnet noise seed per sample (e.g. base + global vehicle index) - makes the result of
-        a vehicle independent of how the vehicles are sharded over ranks; None = the reference's global RNG."""
+        a vehicle independent of how the vehicles are sharded over ranks; None = the reference's global RNG.
+        check: range guard of the split-fp16 path, see `_guarded`."""
+        rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync") else None
+        return self._guarded(self._run, (batch, vehicle_seeds), check, rng)
+
+    @torch.no_grad()
+    def _run(self, batch, vehicle_seeds):
         from . import ops
         B, R = batch["hg_x"].shape[0], batch["hg_x"].shape[-1]
         if B == 0:                                                # a rank whose shard is empty (fewer vehicles than ranks)
@@ -168,8 +210,13 @@ class VehiclePipeline:
         # the ICN's big launches are issued first, on the caller's stream
         return self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)] + ([("inpaint", inpaint)] if self.inpaint else []))
 
+    def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
+                 check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
+        rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync") else None
+        return self._guarded(self._run_clip, (clip, vehicle_seeds), check, rng)
+
     @torch.no_grad()
-    def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> Dict[str, torch.Tensor]:
+    def _run_clip(self, clip, vehicle_seeds):
         """Clip mode = what traj_test does per vehicle over a 6-frame clip: 1x hourglass,
         F x ICN, 1x VUnet appearance half, F x VUnet shape half with the frame-0 appearance code reused
         (trajectory_inference.py:75-79, 182, 387-391, 230-233, 424-426) - but batched over vehicles AND

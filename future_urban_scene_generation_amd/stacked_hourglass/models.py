@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, pack
-from ..nn_base import BNP, ConvP, FusedNet, dev_vec
+from ..nn_base import BNP, ConvP, FusedNet, dev_vec, entry_point
 
 
 class Bottleneck(nn.Module):
@@ -155,6 +155,7 @@ class HourglassNet(FusedNet):
         low3 = self._seq(hp[n - 1][2], low2)
         return ops.upsample2_add(low3, up1)
 
+    @entry_point
     def forward(self, x: torch.Tensor) -> Dict[str, List[torch.Tensor]]:
         P = self._ensure(x)
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 64 or x.shape[3] % 64:

@@ -40,7 +40,7 @@ def synth_state_dict(net: str, schema: Mapping[str, Tuple[Sequence[int], str]], 
     """Build a full state_dict for ``net`` in {'hg','icn','vunet','edge','inpaint'}.
 
     ``schema`` maps state_dict key -> (shape, dtype-name), in state_dict order (the reference's
-    own schema is committed under tests/golden/schema_*.json; the HIP-backed modules expose the
+    own schema is shipped in the package, schemas/schema_*.json; the HIP-backed modules expose the
     identical schema, which tests assert).
     """
     gain = _CONV_GAIN[net]

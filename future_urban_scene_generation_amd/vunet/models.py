@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, pack
-from ..nn_base import FusedNet, WNConvP
+from ..nn_base import FusedNet, WNConvP, entry_point
 from .layers import (Activation, DepthToSpace, DownSample, MyConv2d, NiN, Residual, Sampler, SpaceToDepth,
                      UpSample)
 
@@ -201,6 +201,18 @@ class Vunet_fix_res(FusedNet):
             gens.append(g)
         self.__dict__["_vehicle_gens"] = gens
 
+    def _rng_snapshot(self):
+        """State of the CPU generators the samplers draw from (nn_base.entry_point rewinds them before a repeat)."""
+        gens = self.__dict__.get("_vehicle_gens")
+        return (torch.get_rng_state(), None if gens is None else [g.get_state() for g in gens])
+
+    def _rng_restore(self, snap) -> None:
+        torch.set_rng_state(snap[0])
+        gens = self.__dict__.get("_vehicle_gens")
+        if gens is not None and snap[1] is not None:
+            for g, st in zip(gens, snap[1]):
+                g.set_state(st)
+
     @staticmethod
     def _fill_noise(buf, shapes, gens=None):
         """Writes the N(0,1) draws for `shapes` (in order) into the flat host buffer `buf`; returns
@@ -295,6 +307,7 @@ class Vunet_fix_res(FusedNet):
         return x, ops.depth_to_space2(mus), ops.depth_to_space2(zs)
 
     # ------------------------------------------------------------------ reference entry points
+    @entry_point
     def forward_enc_up(self, x):
         self._ensure(x)
         x = ops.as_nhwc(x)
@@ -309,6 +322,7 @@ class Vunet_fix_res(FusedNet):
         skips.append(self._nin("app_skip_4_c", x))
         return outputs, skips
 
+    @entry_point
     def forward_dec_up(self, x):
         self._ensure(x)
         x = ops.as_nhwc(x)
@@ -323,6 +337,7 @@ class Vunet_fix_res(FusedNet):
             skips += [self._nin(f"shape_skip_{i}_b", sl[-2]), self._nin(f"shape_skip_{i}_c", sl[-1])]
         return [x], skips
 
+    @entry_point
     def forward_enc_down(self, enc_up_outputs: Sequence[torch.Tensor], skips: Sequence[torch.Tensor]):
         self._ensure(enc_up_outputs[-1])
         P = self._plans
@@ -339,6 +354,7 @@ class Vunet_fix_res(FusedNet):
         mu_1, z_1 = self._sampler("app_decoder_2_b", x, noise[1])
         return [mu_0, mu_1], [z_0, z_1]
 
+    @entry_point
     def forward_dec_down(self, dec_up_outputs, skips: List[torch.Tensor], enc_down_mu=()):
         self._ensure(dec_up_outputs[-1])
         P = self._plans
@@ -372,6 +388,7 @@ class Vunet_fix_res(FusedNet):
         assert not skips
         return x, mu, z
 
+    @entry_point
     def forward(self, y_tilde, x=None, mean_mode="mean_appearance"):
         want = 256 if self.vunet_256 else 128
         assert y_tilde.shape[-1] == want

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops, pack
-from ..nn_base import ConvP, FusedNet, dev_vec
+from ..nn_base import ConvP, FusedNet, dev_vec, entry_point
 
 
 class LayerNorm(nn.Module):
@@ -170,10 +170,12 @@ class G_Resnet(FusedNet):
             return ops.conv_rowsplit(P["head"], y, pre_op=pre_op, pre=pre, pre_bstride=bs, act=L.ACT_TANH)
         return ops.conv(P["head"], y, pre_op=pre_op, pre=pre, pre_bstride=bs, act=L.ACT_TANH, nchw_out=True)
 
+    @entry_point
     def decode(self, content: torch.Tensor) -> torch.Tensor:
         P = self._ensure(content)
         return self._decode(P, ops.as_nhwc(content))
 
+    @entry_point
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         P = self._ensure(image)
         if image.dim() != 4 or image.shape[1] != self.input_nc or image.shape[2] % 4 or image.shape[3] % 4:

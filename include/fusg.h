@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 104
+#define FUSG_VERSION 105
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -79,9 +79,13 @@ typedef enum fusg_store_mode {
 
 /* Arithmetic of the conv contraction.
  * F32:   v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (157 TFLOP/s dense peak).
- * F16X3: operands split into fp16 (hi, lo) pairs, a*w ~= ah*wh + ah*wl + al*wh on
- *        v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~2^-22 relative error per product
- *        (fp32-class; |x| is clamped to 65504), 3 MFMA passes at the fp16 rate. */
+ * F16X3: operands split into fp16 pairs, a*w ~= ah*wh + ah*wl + al'*(wh*2^-11) on v_mfma_f32_32x32x16_f16 with
+ *        fp32 accumulation; al' = (a - ah)*2^11 and the weights carry a per-output-channel power-of-two scale
+ *        (wscale), so every operand in fp16's normal range [2^-14, 2^15) keeps >= 22 significant bits: the
+ *        error against fp64 is at or below that of an fp32 fmaf chain for operand scales 1e-4 .. 1e4
+ *        (tools/emu_split.py, tests/test_gpu_ops.py::test_f16x3_scale_sweep).  3 MFMA passes at the fp16 rate.
+ *        Nothing is clamped: a launch that stages an operand with |x| >= 2^15 (or a non-finite one) sets
+ *        *status = 1 and its output is unspecified; the caller must then redo the work with F32. */
 typedef enum fusg_precision { FUSG_PREC_F32 = 0, FUSG_PREC_F16X3 = 1 } fusg_precision;
 
 typedef enum fusg_tile {       /* workgroup tile (output pixels x output channels); 0 = auto */
@@ -135,7 +139,7 @@ typedef struct fusg_conv_desc {
     int32_t tile;                /* fusg_tile                                                  */
     int32_t ksplit;              /* <=1: no split-K                                            */
     int32_t precision;           /* fusg_precision                                             */
-    const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo)       */
+    const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo) of w * s[n]   */
     /* Optional filter geometry (0 = unknown).  When given and the layer qualifies (F16X3, stride 1,
      * nphase 1, source channels % 32 == 0, qh % 8 == 0, qw % 16 == 0) the halo-tiled kernel
      * is used: taps must then be the dense kh x kw grid in (ky, kx) order with
@@ -171,6 +175,12 @@ typedef struct fusg_conv_desc {
      * phase launches of a transposed convolution) write disjoint slot ranges of one buffer - offset the stats_out
      * pointer by first_slot*cout*2 floats. */
     int32_t        stats_slots;
+    /* F16X3 only.  wscale[cout_pad] = 1 / s[n], s[n] the power of two the channel's weights were multiplied by
+     * before the (hi, lo) split (pack.py: split_f16x3); the epilogue computes acc * wscale[n] + bias[n].
+     * status: one device int32 (caller-owned, zeroed by the caller), set to 1 by the launch when an operand is
+     * outside the split's range - see fusg_precision.  Sticky: the library never clears it. */
+    const float*   wscale;
+    int32_t*       status;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);

@@ -16,11 +16,54 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped (not failed) on a machine without a HIP device."""
+    if torch.cuda.device_count() > 0:              # (device_count does not initialise the HIP runtime)
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+# ---- observed-parity log -----------------------------------------------------------------------------------
+# GPU parity tests record the error they observed (not just pass/fail): {test id: {metric: worst value}}.  At
+# session end the log goes to gpurun_out/parity_observed.json (merged back from the GPU box; the copy judged is
+# committed under profiles/).  The bars asserted in the tests are ~10x these observations.
+PARITY = {}
+_CURRENT = {"id": None}
+
+
+@pytest.fixture(autouse=True)
+def _parity_scope(request):
+    _CURRENT["id"] = request.node.nodeid.split("::", 1)[-1]
+    yield
+    _CURRENT["id"] = None
+
+
+def record(metric, value, worst=max):
+    """Keep the worst observed `value` of `metric` for the running test."""
+    tid = _CURRENT["id"] or "?"
+    d = PARITY.setdefault(tid, {})
+    d[metric] = float(value) if metric not in d else float(worst(d[metric], value))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY:
+        return
+    out = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_observed.json"), "w") as f:
+            json.dump({"exitstatus": int(exitstatus), "observed": PARITY}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def load_schema(net):
-    from collections import OrderedDict
-    with open(os.path.join(GOLD, f"schema_{net}.json")) as f:
-        raw = json.load(f, object_pairs_hook=OrderedDict)
-    return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
+    """state_dict schema dumped from the reference's modules (shipped in the package: schemas/schema_<net>.json)."""
+    from future_urban_scene_generation_amd.pipeline import load_schema as _ls
+    return _ls(net)
 
 
 def load_golden(name):

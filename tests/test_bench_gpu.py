@@ -1,0 +1,38 @@
+"""GPU box: `python bench.py --gpus 2` starts its two ranks itself and reports n_gpus 2.  On a one-GPU box the ranks
+share the card and the gather is staged through gloo (FUSG_DIST_BACKEND=gloo); with two or more cards it is RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus2_self_spawn():
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has initialised HIP: the launcher is started only from a process that has not")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["FUSG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--res", "128", "--settle-s", "0", "--no-cpu-baseline", "--no-clip"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+    assert set(line["precision_legs"]) == {"f16x3", "f32"}
+    assert line["config"]["batch_per_gpu"] == 2 and line["scaling"] == "weak"
+    assert line["per_rank_crops_per_s"]["min"] <= line["per_rank_crops_per_s"]["max"]
+    # strong-scaling mode (BASELINE configs[3] shape): 5 vehicles over 2 ranks, ragged shards
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--vehicles", "5", "--steps", "2",
+                        "--warmup", "1", "--res", "128", "--settle-s", "0", "--no-cpu-baseline", "--no-clip", "--no-prof",
+                        "--precision", "f16x3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "5 vehicles" in line["config"]["workload"]

@@ -1,8 +1,10 @@
 """GPU parity: the HIP-backed drop-in modules against the CPU oracle (same synthetic weights, same
 seeded inputs) and against the committed golden vectors produced by the reference itself.
 
-Tolerances (fp32 MFMA path; only the summation order differs from the reference's CPU kernels):
-  * heat-maps / generator outputs: max |diff| <= 2e-3 relative to the tensor's dynamic range;
+Bars (both contraction paths; only the summation order differs from the reference's CPU kernels).  Every
+comparison records the error it observed (conftest.record -> profiles/r02_parity.json); the bars are ~10x the worst
+observation of the round, not a generic tolerance:
+  * heat-maps / generator outputs: max |diff| relative to the tensor's largest magnitude < TOL;
   * 64x64 heat-map argmax indices and get_maxima floats: bit-exact;
   * to_image-quantised uint8 images: |diff| <= 1 LSB and SSIM >= 0.999 (north_star bar).
 """
@@ -25,7 +27,7 @@ def precision(request):
     _ops.set_precision(old)
 
 import oracle                                                              # noqa: E402
-from conftest import load_golden, load_schema, synth_sd                    # noqa: E402
+from conftest import load_golden, load_schema, record, synth_sd            # noqa: E402
 from future_urban_scene_generation_amd import ops                          # noqa: E402
 from future_urban_scene_generation_amd.edgeconnect.models import EdgeModel, InpaintingModel   # noqa: E402
 from future_urban_scene_generation_amd.edgeconnect.networks import EdgeGenerator, InpaintGenerator   # noqa: E402
@@ -35,13 +37,26 @@ from future_urban_scene_generation_amd.vunet.models import Vunet_fix_res   # noq
 from future_urban_scene_generation_amd.warp_learn.models import G_Resnet   # noqa: E402
 
 DEV = "cuda:0"
+TOL = 2e-4            # raw network outputs, relative to the tensor's largest magnitude (observed: profiles/r02_parity.json)
+TOL_ILL = 2e-3        # ICN on the deliberately ill-conditioned fixtures (InstanceNorm of near-constant planes)
 
 
-def _rel(got, ref):
+def _rel(got, ref, what="rel_err"):
     got = got.detach().to("cpu").double()
     ref = torch.as_tensor(ref).double()
     assert got.shape == ref.shape, (got.shape, ref.shape)
-    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+    r = float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+    record(what, r)
+    return r
+
+
+def _u8(got, ref):
+    """uint8 images: records and returns (max |diff| in LSB, SSIM)."""
+    d = int(np.abs(got.astype(int) - ref.astype(int)).max())
+    s = float(oracle.ssim(got, ref))
+    record("u8_max_diff", d)
+    record("ssim_min", s, worst=min)
+    return d, s
 
 
 def _build(net):
@@ -78,8 +93,8 @@ def test_hourglass(tag, B, R):
     hm = out["heatmaps"]
     assert hm[1].is_contiguous() and tuple(hm[1].shape) == (B, 12, R // 4, R // 4)
     ref = oracle.hourglass_forward(synth_sd("hg"), x)["heatmaps"]
-    assert _rel(hm[0], ref[0]) < 2e-3 and _rel(hm[1], ref[1]) < 2e-3
-    assert _rel(hm[1], g["hm1"]) < 2e-3
+    assert _rel(hm[0], ref[0]) < TOL and _rel(hm[1], ref[1]) < TOL
+    assert _rel(hm[1], g["hm1"]) < TOL
     # integer contract: bit-exact argmax / get_maxima vs the reference's golden values
     idx = ops.argmax_hw(hm[1]).cpu().numpy().astype(np.int64)
     assert np.array_equal(idx, g["argmax"])
@@ -96,11 +111,10 @@ def test_icn(tag, B, R):
     out = model("icn")(x.to(DEV))
     assert out.is_contiguous() and tuple(out.shape) == (B, 3, R, R)
     ref = oracle.icn_forward(synth_sd("icn"), x)
-    assert _rel(out, ref) < 2e-3
-    assert _rel(out, g["out"]) < 2e-3
-    img = ops.to_image_u8(out).cpu().numpy()
-    assert np.abs(img.astype(int) - g["img_u8"].astype(int)).max() <= 1
-    assert oracle.ssim(img, g["img_u8"]) >= 0.999
+    assert _rel(out, ref) < TOL
+    assert _rel(out, g["out"]) < TOL
+    d, ss = _u8(ops.to_image_u8(out).cpu().numpy(), g["img_u8"])
+    assert d <= 1 and ss >= 0.999
 
 
 @pytest.mark.parametrize("tag,B,R", [("vunet_b1_r256", 1, 256), ("vunet_b2_r128", 2, 128)])
@@ -116,7 +130,7 @@ def test_vunet_traj_sequence(tag, B, R, manifest):
     sums = np.array([float(t.cpu().double().sum()) for t in ds])
     np.testing.assert_allclose(sums, g["skip_sums"], rtol=2e-3, atol=float(np.max(g["skip_abs"])) * 1e-5)
     for k in (0, 5, 13):
-        assert _rel(ds[k][:, :, :8, :8], g[f"skip{k}_corner"]) < 2e-3
+        assert _rel(ds[k][:, :, :8, :8], g[f"skip{k}_corner"]) < TOL
     xt, mu_s, z_s = vu.forward_dec_down(do, ds, mu_app)
     assert ds == []
     assert xt.is_contiguous()
@@ -124,15 +138,14 @@ def test_vunet_traj_sequence(tag, B, R, manifest):
                     ("mu_app0", mu_app[0]), ("mu_app1", mu_app[1]), ("z_app0", z_app[0]), ("z_app1", z_app[1]),
                     ("dec_out", do[0]), ("x_tilde", xt), ("mu_s0", mu_s[0]), ("mu_s1", mu_s[1]),
                     ("z_s0", z_s[0]), ("z_s1", z_s[1])]:
-        assert _rel(t, g[name]) < 2e-3, name
-    img = ops.to_image_u8(xt).cpu().numpy()
-    assert np.abs(img.astype(int) - g["img_u8"].astype(int)).max() <= 1
-    assert oracle.ssim(img, g["img_u8"]) >= 0.999
+        assert _rel(t, g[name]) < TOL, name
+    d, ss = _u8(ops.to_image_u8(xt).cpu().numpy(), g["img_u8"])
+    assert d <= 1 and ss >= 0.999
     # later frame (appearance code reused)
     y2 = synth_inputs("vunet", B, R, 1)["y_tilde"]
     torch.manual_seed(manifest["cases"][tag]["later_seed"])
     do2, ds2 = vu.forward_dec_up(y2.to(DEV))
-    assert _rel(vu.forward_dec_down(do2, ds2, mu_app)[0], g["x_tilde_later"]) < 2e-3
+    assert _rel(vu.forward_dec_down(do2, ds2, mu_app)[0], g["x_tilde_later"]) < TOL
 
 
 def test_vunet_forward_entry_and_nchw_inputs(manifest):
@@ -141,7 +154,7 @@ def test_vunet_forward_entry_and_nchw_inputs(manifest):
     i = synth_inputs("vunet", 1, 256)
     torch.manual_seed(manifest["cases"]["vunet_b1_r256"]["fwd_seed"])
     xt, mu_app, mu_shape = vu(i["y_tilde"].to(DEV), i["x"].to(DEV))
-    assert _rel(xt, g["fwd_x_tilde"]) < 2e-3 and _rel(mu_shape[0], g["fwd_mu_shape0"]) < 2e-3
+    assert _rel(xt, g["fwd_x_tilde"]) < TOL and _rel(mu_shape[0], g["fwd_mu_shape0"]) < TOL
     # callers may hand back plain NCHW copies of the intermediate tensors
     torch.manual_seed(5)
     do, ds = vu.forward_dec_up(i["y_tilde"].to(DEV))
@@ -162,16 +175,15 @@ def test_edgeconnect(tag, B, R):
     em, im = em.to(DEV).eval(), im.to(DEV).eval()
     gray, edge, mask, img = (i[k].to(DEV) for k in ("gray", "edge", "mask", "img"))
     e = em(gray, edge, mask).detach()
-    assert _rel(e, g["edge_out"]) < 2e-3
+    assert _rel(e, g["edge_out"]) < TOL
     p = im(img, e, mask)
-    assert _rel(p, g["inpaint_out"]) < 2e-3
-    u8 = ops.merge_u8(p, img, mask).cpu().numpy()
-    assert np.abs(u8.astype(int) - g["merged_u8"].astype(int)).max() <= 1
-    assert oracle.ssim(u8, g["merged_u8"]) >= 0.999
+    assert _rel(p, g["inpaint_out"]) < TOL
+    d, ss = _u8(ops.merge_u8(p, img, mask).cpu().numpy(), g["merged_u8"])
+    assert d <= 1 and ss >= 0.999
     # bare generators behave like the wrappers' generator
     m = i["mask"]
     e2 = model("edge")(torch.cat((i["gray"] * (1 - m) + m, i["edge"] * (1 - m), m), 1).to(DEV))
-    assert _rel(e2, g["edge_out"]) < 2e-3
+    assert _rel(e2, g["edge_out"]) < TOL
 
 
 def test_modules_refuse_cpu_and_training():
@@ -204,7 +216,7 @@ def test_high_res_512(precision):
     x = synth_inputs("icn", 1, 512)["x"]
     out = model("icn")(x.to(DEV))
     ref = oracle.icn_forward(synth_sd("icn"), x)
-    assert tuple(out.shape) == (1, 3, 512, 512) and _rel(out, ref) < 2e-3
+    assert tuple(out.shape) == (1, 3, 512, 512) and _rel(out, ref) < TOL
     assert oracle.ssim(ops.to_image_u8(out).cpu().numpy(), oracle.to_image_u8(ref)) >= 0.999
     hx = synth_inputs("hg", 1, 512)["x"]
     hm = model("hg")(hx.to(DEV))["heatmaps"][-1]
@@ -300,7 +312,7 @@ def test_non_square_and_odd_tiles(H, W, precision):
     x = torch.rand(2, 21, H, W, generator=g) * 2 - 1
     out = model("icn")(x.to(DEV))
     ref = oracle.icn_forward(synth_sd("icn"), x)
-    assert tuple(out.shape) == (2, 3, H, W) and _rel(out, ref) < 2e-3
+    assert tuple(out.shape) == (2, 3, H, W) and _rel(out, ref) < TOL
     img = torch.rand(2, 3, H, W, generator=g)
     gray = img.mean(1, keepdim=True)
     edge = (torch.rand(2, 1, H, W, generator=g) < 0.05).float()
@@ -310,12 +322,106 @@ def test_non_square_and_odd_tiles(H, W, precision):
     em.generator.load_state_dict(synth_sd("edge"))
     em = em.to(DEV).eval()
     e = em(gray.to(DEV), edge.to(DEV), mask.to(DEV))
-    assert _rel(e, oracle.edge_model_forward(synth_sd("edge"), gray, edge, mask)) < 2e-3
+    assert _rel(e, oracle.edge_model_forward(synth_sd("edge"), gray, edge, mask)) < TOL
 
 
 def test_hourglass_non_square(precision):
     x = synth_inputs("hg", 1, 256)["x"][:, :, :128, :192].contiguous()
     hm = model("hg")(x.to(DEV))["heatmaps"][-1]
     ref = oracle.hourglass_forward(synth_sd("hg"), x)["heatmaps"][-1]
-    assert tuple(hm.shape) == (1, 12, 32, 48) and _rel(hm, ref) < 2e-3
+    assert tuple(hm.shape) == (1, 12, 32, 48) and _rel(hm, ref) < TOL
     assert np.array_equal(ops.argmax_hw(hm).cpu().numpy(), oracle.heatmap_argmax(ref))
+
+
+def test_out_of_range_input_falls_back_to_exact_fp32(precision):
+    """no silent saturation.  A network input holding 1e5 (outside the fp16 split's range) makes the
+    first f16x3 launch raise the status word; the entry point then redoes the call on the exact-fp32 path, so the
+    caller gets bit for bit what precision="f32" gives - for a plain forward and for the VUnet (noise rewound, the
+    consumed `skips` list restored)."""
+    if precision != "f16x3":
+        pytest.skip("f16x3 only")
+    x = synth_inputs("icn", 1, 64)["x"].clone()
+    x[0, 3, 10, 10] = 1e5
+    got = model("icn")(x.to(DEV))
+    with ops.precision("f32"):
+        want = model("icn")(x.to(DEV))
+    assert torch.equal(got, want)
+    assert not ops.range_exceeded(DEV)
+    vu = model("vunet")
+    i = synth_inputs("vunet", 1, 128)
+    y = i["y_tilde"].clone()
+    y[0, 1, 5, 5] = -7e4
+    torch.manual_seed(3)
+    do, ds = vu.forward_dec_up(y.to(DEV))
+    n_skips = len(ds)
+    xt = vu.forward_dec_down(do, ds)[0]
+    assert ds == [] and n_skips == 14
+    with ops.precision("f32"):
+        torch.manual_seed(3)
+        do2, ds2 = vu.forward_dec_up(y.to(DEV))
+        want = vu.forward_dec_down(do2, ds2)[0]
+    assert torch.equal(xt, want)
+    # the pipeline checks a whole pass (per-network checks deferred) and redoes it in fp32
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    pipe = VehiclePipeline(DEV)
+    batch = synth_batch(2, 128, DEV)
+    batch["icn_x"][1, 0, 0, 0] = 1e6
+    seeds = [5, 6]
+    out = pipe.run(batch, vehicle_seeds=seeds)
+    with ops.precision("f32"):
+        want = pipe.run(batch, vehicle_seeds=seeds)
+    for k in out:
+        assert torch.equal(out[k], want[k]), k
+    pipe.run(batch, vehicle_seeds=seeds, check="async")
+    assert pipe.finish() is True and pipe.finish() is False
+
+
+def test_grad_enabled_calls_and_detach():
+    """traj_test calls the ICN / VUnet / EdgeConnect modules WITH grad enabled and detaches the result
+    (trajectory_inference.py:124, planes_utils.py:105): the drop-ins must neither need no_grad nor return tensors
+    that break .detach()/.cpu()/.numpy()."""
+    with torch.enable_grad():
+        x = synth_inputs("icn", 1, 64)["x"].to(DEV)
+        out = model("icn")(x)
+        assert not out.requires_grad
+        a = out.detach().to("cpu").numpy()
+        i = synth_inputs("vunet", 1, 128)
+        vu = model("vunet")
+        torch.manual_seed(1)
+        eo, es = vu.forward_enc_up(i["x"].to(DEV))
+        mu, _ = vu.forward_enc_down(eo, es)
+        do, ds = vu.forward_dec_up(i["y_tilde"].to(DEV))
+        xt = vu.forward_dec_down(do, ds, mu)[0]
+        b = xt.detach().to("cpu").numpy()
+        e = synth_inputs("edge", 1, 64)
+        em = EdgeModel(None)
+        em.generator.load_state_dict(synth_sd("edge"))
+        em = em.to(DEV).eval()
+        c = em(e["gray"].to(DEV), e["edge"].to(DEV), e["mask"].to(DEV)).detach().cpu().numpy()
+    with torch.no_grad():
+        a2 = model("icn")(x).cpu().numpy()
+    assert np.array_equal(a, a2) and np.isfinite(b).all() and np.isfinite(c).all()
+    for p in model("icn").parameters():
+        assert p.requires_grad and p.grad is None
+
+
+def test_edgeconnect_checkpoint_roundtrip(tmp_path):
+    """EdgeConnect's checkpoint contract (edgeconnect/models.py:17-38): {'iteration', 'generator'} at
+    <PATH>/<name>_gen.pth, read back by BaseModel.load() into a fresh model."""
+    cfg = Namespace(PATH=str(tmp_path))
+    src = InpaintingModel(cfg)
+    src.generator.load_state_dict(synth_sd("inpaint"))
+    src.iteration = 1234
+    src.save()
+    blob = torch.load(str(tmp_path / "InpaintingModel_gen.pth"), map_location="cpu")
+    assert set(blob.keys()) == {"iteration", "generator"} and list(blob["generator"].keys()) == list(load_schema("inpaint").keys())
+    dst = InpaintingModel(cfg)
+    dst.load()
+    assert dst.iteration == 1234
+    i = synth_inputs("edge", 1, 64)
+    args = [i[k].to(DEV) for k in ("img", "edge", "mask")]
+    assert torch.equal(src.to(DEV).eval()(*args), dst.to(DEV).eval()(*args))
+    em = EdgeModel(Namespace(PATH=str(tmp_path / "absent")))
+    before = {k: v.clone() for k, v in em.generator.state_dict().items()}
+    em.load()                                                     # no file: the initial weights stay
+    assert all(torch.equal(v, em.generator.state_dict()[k]) for k, v in before.items())

@@ -402,3 +402,74 @@ def test_rowsplit_head(cout, act, fn):
     got = ops.conv_rowsplit(plan, _nhwc(x), pre_op=L.PRE_AFFINE_RELU, pre=(sc.to(dev()), sh.to(dev())), pre_bstride=64, act=act)
     assert got.is_contiguous()
     _close(got, ref)
+
+
+# ---- split-fp16 contraction: accuracy over operand scale, and the range guard -----------------------------------
+SWEEP_LAYERS = [   # name, cin, cout, k, pad, H, W, pre-op, expected kernel family (fusg_last_conv_kernel)
+    ("halo_k2304", 256, 64, 3, 1, 16, 16, L.PRE_NONE, 2),
+    ("halo_k2304_relu", 256, 64, 3, 1, 16, 16, L.PRE_RELU, 2),
+    ("generic_k2304", 256, 64, 3, 1, 15, 17, L.PRE_NONE, 1),
+    ("generic_k2304_elu", 256, 64, 3, 1, 15, 17, L.PRE_ELU, 1),
+    ("tapunit_k1176", 24, 32, 7, 3, 16, 16, L.PRE_NONE, 4),
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,k,pad,H,W,pre,family", SWEEP_LAYERS)
+def test_f16x3_scale_sweep(name, cin, cout, k, pad, H, W, pre, family, precision):
+    """the split-fp16 contraction must stay fp32-class when the operands are not O(1).  For operand
+    scales {1e-3, 1e-2, 1, 1e2} x {2e-3, 2e-2, 1} the error against an fp64 reference (normalised by |a| * |w|) of the
+    f16x3 kernel is compared with that of the exact-fp32 MFMA kernel on the same launch: bar = 4x (observed ~0.5x,
+    profiles/r02_parity.json)."""
+    if precision != "f16x3":
+        pytest.skip("compares both kernels itself")
+    from conftest import record
+    worst = 0.0
+    for sa in (1e-3, 1e-2, 1.0, 1e2):
+        for sw in (2e-3, 2e-2, 1.0):
+            x = _rand(2, cin, H, W, seed=11, scale=sa)
+            w = _rand(cout, cin, k, k, seed=12, scale=sw)
+            b = _rand(cout, seed=13, scale=sa * sw)
+            plan = pack.pack_conv(w, b, pad=pad)
+            xp = {L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre].double()
+            ref = F.conv2d(xp, w.double(), b.double(), padding=pad)
+            den = F.conv2d(xp.abs(), w.double().abs(), None, padding=pad) + 1e-300
+            xin = _nhwc(x)
+            got3 = ops.conv(plan, xin, pre_op=pre, precision="f16x3")
+            assert ops.last_conv_kernel() == family, (name, ops.last_conv_kernel())
+            assert not ops.range_exceeded(dev())
+            got32 = ops.conv(plan, xin, pre_op=pre, precision="f32")
+            e3 = float(((got3.cpu().double() - ref).abs() / den).max())
+            e32 = float(((got32.cpu().double() - ref).abs() / den).max())
+            record("f16x3_err_max", e3)
+            record("f32_err_max", e32)
+            record("ratio_max", e3 / e32)
+            worst = max(worst, e3 / e32)
+            assert e3 <= 4 * e32 + 1e-9, (name, sa, sw, e3, e32)
+    assert worst < 4
+
+
+@pytest.mark.parametrize("name,cin,cout,k,pad,H,W,pre,family", SWEEP_LAYERS[::2])
+def test_f16x3_out_of_range_raises_status(name, cin, cout, k, pad, H, W, pre, family, precision):
+    """An operand the split cannot represent (|x| >= 2^15, inf) is never clamped silently: the launch raises the
+    caller-owned status word (fusg_conv_desc.status)."""
+    if precision != "f16x3":
+        pytest.skip("f16x3 only")
+    w = _rand(cout, cin, k, k, seed=2, scale=0.02)
+    plan = pack.pack_conv(w, None, pad=pad)
+    for bad in (1e5, -4e4, float("inf")):
+        x = _rand(1, cin, H, W, seed=1)
+        assert not ops.range_exceeded(dev())
+        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+        assert not ops.range_exceeded(dev())                     # in range: status stays clear
+        x[0, cin // 2, H // 2, W // 3] = bad
+        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+        assert ops.last_conv_kernel() == family
+        assert ops.range_exceeded(dev())                         # raised (and cleared by the read)
+        assert not ops.range_exceeded(dev())
+    # just inside the range: exact handling, no flag
+    x = _rand(1, cin, H, W, seed=1)
+    x[0, 0, 0, 0] = 32767.0
+    got = ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+    assert not ops.range_exceeded(dev())
+    ref = F.conv2d({L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre].double(), w.double(), None, padding=pad)
+    assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-6

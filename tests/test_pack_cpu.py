@@ -164,22 +164,34 @@ def test_rowsplit_head_matches_conv():
 
 
 def test_f16x3_split_is_fp32_class():
-    """The split-fp16 contraction a*w ~= ah*wh + ah*wl + al*wh (csrc/conv_kernel_h3.h): emulate it with
-    exact fp64 products of the fp16 parts and compare with plain fp16 and with fp32 rounding."""
+    """The split-fp16 contraction a*w ~= ah*wh + ah*wl + al'*(wh*2^-11) (csrc/conv_kernel_h3.h): emulate it with exact
+    fp64 products of the fp16 parts, over the operand scales of the GPU sweep (test_gpu_ops.py), and compare with plain
+    fp16 and with fp32 rounding.  tools/emu_split.py is the long form of this test (fp32 fmaf chain, bf16 splits)."""
     g = torch.Generator().manual_seed(0)
-    a = torch.randn(256, 512, generator=g)
-    w = torch.randn(512, 64, generator=g) * 0.05
-    exact = a.double() @ w.double()
-    wsplit = pack.split_f16x3(w.t().contiguous()[None])[0]              # [2, 64, 512] (hi, lo)
-    wh, wl = wsplit[0].t().double(), wsplit[1].t().double()
-    ah = (a.view(torch.int32) & -8192).view(torch.float32)             # kernel: top 11 significant bits
-    al = (a - ah).half()
-    ah, al = ah.double(), al.double()
-    x3 = ah @ wh + ah @ wl + al @ wh
-    scale = (a.abs().double() @ w.abs().double())
-    e3 = ((x3 - exact).abs() / scale).max().item()
-    e1 = ((a.half().double() @ w.half().double() - exact).abs() / scale).max().item()
-    e32 = (((a @ w).double() - exact).abs() / scale).max().item()
-    assert e3 < 2e-6 and e3 < e1 / 200, (e3, e1, e32)                  # ~2^-21 vs fp16's ~2^-11
-    big = a.abs() >= 2.0 ** -14                                        # fp16 normal range
-    assert (ah.float().half().float() == ah.float())[big].all()        # hi is exactly representable in fp16 there
+    for sa in (1e-3, 1.0, 1e2):
+        for sw in (2e-3, 1.0):
+            a = torch.randn(64, 512, generator=g) * sa
+            w = torch.randn(512, 64, generator=g) * sw
+            exact = a.double() @ w.double()
+            wsplit, inv = pack.split_f16x3(w.t().contiguous()[None])        # [1, 2, 64, 512] (hi, lo), [64]
+            wh, wl = wsplit[0, 0].t().double(), wsplit[0, 1].t().double()
+            # per-channel power-of-two scale, exact to undo; the largest weight of a channel sits in [2^13, 2^14)
+            assert torch.equal(torch.frexp(inv)[0], torch.full_like(inv, 0.5))
+            top = (wh.abs().amax(dim=0))
+            assert bool(((top >= 2.0 ** 13) & (top <= 2.0 ** 14)).all())
+            # (hi, lo) carry >= 22 significant bits of the channel's largest weight
+            assert float((((wh + wl) * inv.double()) - w.double()).abs().max() / w.abs().max()) < 2.0 ** -21
+            whs = (wh * 2.0 ** -11).half().double()                          # third term's B operand (v_pk_mul_f16)
+            # kernel: hi = round toward zero to fp16, lo' = (a - hi) * 2^11 rounded to fp16
+            hi_rn = a.half()
+            over = hi_rn.float().abs() > a.abs()
+            hi = torch.where(over, (hi_rn.view(torch.int16) - 1).view(torch.float16), hi_rn)
+            assert bool((hi.float().abs() <= a.abs()).all())
+            ah = hi.double()
+            al = ((a.double() - ah) * 2048.0).float().half().double()
+            x3 = (ah @ wh + ah @ wl + al @ whs) * inv.double()
+            scale = (a.abs().double() @ w.abs().double())
+            e3 = ((x3 - exact).abs() / scale).max().item()
+            e1 = ((a.half().double() @ w.half().double() - exact).abs() / scale).max().item()
+            e32 = (((a @ w).double() - exact).abs() / scale).max().item()
+            assert e3 < 1e-7 and e3 < e1 / 200, (sa, sw, e3, e1, e32)       # ~2^-24 at every scale vs fp16's ~2^-11

@@ -65,7 +65,7 @@ def build():
     sds = {}
     for name, net in nets.items():
         schema = schema_of(net.state_dict())
-        with open(os.path.join(GOLD, f"schema_{name}.json"), "w") as f:
+        with open(os.path.join(REPO, "future_urban_scene_generation_amd", "schemas", f"schema_{name}.json"), "w") as f:
             json.dump({k: [list(s), d] for k, (s, d) in schema.items()}, f, indent=0)
         sd = synth_state_dict(name, schema, SEED)
         net.load_state_dict(sd)
