@@ -1,6 +1,9 @@
 // libfusg: error reporting, version, and the opt-in per-kernel HIP-event profiler.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 #include "common.h"
 
@@ -15,13 +18,40 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+hipError_t ensure_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_pair(dev, fn);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert(key);
+    return e;
+}
+
+const EnvSwitches& env_switches() {
+    static const EnvSwitches sw = [] {
+        EnvSwitches s;
+        s.no_vec_epi = getenv("FUSG_NO_VEC_EPI") != nullptr;
+        s.no_halo = getenv("FUSG_NO_HALO") != nullptr;
+        s.halo_minwg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
+        s.halo_bn = getenv("FUSG_HALO_BN") ? atoi(getenv("FUSG_HALO_BN")) : 0;
+        return s;
+    }();
+    return sw;
+}
+
 // ---- profiler: event pairs recorded on the launch stream, resolved lazily in fusg_prof_read ----
 struct ProfKind {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> pool;
     double ms = 0.0, flops = 0.0;
     long launches = 0;
-    hipEvent_t cur_begin = nullptr;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> open;    // begin events not yet closed, by launch stream (two host
+                                                             // threads or two streams may be between begin and end at once)
 };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
@@ -38,21 +68,25 @@ void prof_begin(int kind, hipStream_t s, double flops) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfKind& k = g_kinds[kind];
-    k.cur_begin = get_event(k);
+    hipEvent_t b = get_event(k);
     k.flops += flops;
     k.launches += 1;
-    (void)hipEventRecord(k.cur_begin, s);
+    (void)hipEventRecord(b, s);
+    k.open.emplace_back(s, b);
 }
 
 void prof_end(int kind, hipStream_t s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfKind& k = g_kinds[kind];
-    if (!k.cur_begin) return;
-    hipEvent_t e = get_event(k);
-    (void)hipEventRecord(e, s);
-    k.pending.emplace_back(k.cur_begin, e);
-    k.cur_begin = nullptr;
+    for (size_t i = k.open.size(); i-- > 0;) {
+        if (k.open[i].first != s) continue;
+        hipEvent_t e = get_event(k);
+        (void)hipEventRecord(e, s);
+        k.pending.emplace_back(k.open[i].second, e);
+        k.open.erase(k.open.begin() + (long)i);
+        return;
+    }
 }
 
 }  // namespace fusg
@@ -76,7 +110,9 @@ extern "C" void fusg_prof_reset(void) {
     for (ProfKind& k : g_kinds) {
         for (auto& pr : k.pending) { k.pool.push_back(pr.first); k.pool.push_back(pr.second); }
         k.pending.clear();
-        k.ms = 0.0; k.flops = 0.0; k.launches = 0; k.cur_begin = nullptr;
+        for (auto& o : k.open) k.pool.push_back(o.second);
+        k.open.clear();
+        k.ms = 0.0; k.flops = 0.0; k.launches = 0;
     }
 }
 

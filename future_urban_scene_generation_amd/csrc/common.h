@@ -46,6 +46,15 @@ static inline bool same_shape(const fusg_tensor& a, const fusg_tensor& b) {
     return same_nhw(a, b) && a.c == b.c;
 }
 
+// One-time, per-device opt-in of a kernel to `bytes` of dynamic LDS (hipFuncSetAttribute is a driver call: it is
+// made once per (device, kernel), not per launch).  Thread-safe.  (api.hip)
+hipError_t ensure_dyn_lds(const void* fn, int bytes);
+
+// Development switches, read from the environment ONCE (first use): FUSG_NO_VEC_EPI, FUSG_NO_HALO,
+// FUSG_HALO_MINWG, FUSG_HALO_BN (tools/README.md).  (api.hip)
+struct EnvSwitches { bool no_vec_epi, no_halo; long halo_minwg; int halo_bn; };
+const EnvSwitches& env_switches();
+
 // profiler (api.hip)
 void prof_begin(int kind, hipStream_t s, double flops);
 void prof_end(int kind, hipStream_t s);

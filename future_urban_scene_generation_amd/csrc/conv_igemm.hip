@@ -46,7 +46,8 @@ static const float* zero_line() {
     if (!z[dev]) {
         float* q = nullptr;
         if (hipMalloc((void**)&q, 256) != hipSuccess) return nullptr;
-        if (hipMemset(q, 0, 256) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        // one-time: the memset runs on the null stream, which non-blocking streams do not wait for
+        if (hipMemset(q, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(q); return nullptr; }
         z[dev] = q;
     }
     return z[dev];
@@ -207,7 +208,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         auto vec_ok = [](const fusg_tensor& t) {
             return t.sc == 1 && (((uintptr_t)t.data) & 15) == 0 && t.sw % 4 == 0 && t.sh % 4 == 0 && t.sn % 4 == 0;
         };
-        bool v = d->cout % 4 == 0 && d->dst_c_off % 4 == 0 && vec_ok(o) && getenv("FUSG_NO_VEC_EPI") == nullptr;
+        bool v = d->cout % 4 == 0 && d->dst_c_off % 4 == 0 && vec_ok(o) && !env_switches().no_vec_epi;
         if (d->store_mode == FUSG_STORE_D2S) v = v && (d->cout / 4) % 4 == 0;
         if (d->res0.data) v = v && vec_ok(d->res0);
         if (d->res1.data) v = v && vec_ok(d->res1);
@@ -246,7 +247,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
-                         getenv("FUSG_NO_HALO") == nullptr && (d->q_oy | d->q_ox) == 0 && d->wfrag_order != 2 &&
+                         !env_switches().no_halo && (d->q_oy | d->q_ox) == 0 && d->wfrag_order != 2 &&
                          !(d->wfrag_order == 1 && (x0.h % 2 != 0 || x0.w % 2 != 0 || d->stride != 2));   // odd sizes: generic gather
     // few-channel k x k layers (the 7x7 stems): tap-unit kernel (conv_kernel_tapunit.h)
     if (d->wfrag_order == 2) {
@@ -256,7 +257,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                         d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 && d->c0k >= 4 && d->c0k <= 24 && d->kh >= 1 &&
                         d->kw >= 1 && d->dil == 1 && d->qh % 8 == 0 && d->qw % 16 == 0 && nunits <= 160 &&
                         d->k_pad >= d->kh * d->kw * d->c0k && (d->q_oy | d->q_ox) == 0 && !d->tile_list &&
-                        getenv("FUSG_NO_HALO") == nullptr;
+                        !env_switches().no_halo;
         if (ok) {
             TapUnitK h;
             memset(&h, 0, sizeof(h));
@@ -299,11 +300,11 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.nt32 = d->cout_pad / 32;
         int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
         {   // small grids: narrower column tiles until the launch has enough workgroups to fill the chip
-            static const long min_wg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
+            const long min_wg = env_switches().halo_minwg;
             const long mt = (long)x0.n * (d->tile_list ? d->tile_count : (d->qh / 8) * (d->qw / 16));
             while (bn > 32 && mt * (d->cout_pad / bn) < min_wg) bn /= 2;
         }
-        if (const char* ev = getenv("FUSG_HALO_BN")) { const int v = atoi(ev); if ((v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v; }
+        if (const int v = env_switches().halo_bn; (v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v;
         h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
         h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
@@ -336,7 +337,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c.MT = (int)x0.n * h.tiles_per_img;
         if (d->tile_list) {
-            if (d->tile_count > h.tiles_per_img) { set_error("conv2d: tile_count %d > %d patches per image", d->tile_count, h.tiles_per_img); return FUSG_ERR_INVALID; }
+            if (d->tile_count > h.tiles_per_img) { set_error("conv2d: tile_count %d > %d patches per image", d->tile_count, h.tiles_per_img); prof_end(0, s); return FUSG_ERR_INVALID; }
             h.tile_list = d->tile_list; h.tile_count = d->tile_count;
             h.c.MT = (int)x0.n * d->tile_count;
         }

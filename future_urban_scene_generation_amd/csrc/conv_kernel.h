@@ -450,12 +450,7 @@ hipError_t launch_tile(const ConvK& k, dim3 grid, hipStream_t s, int pk, bool ge
     else if (pk == PK_ELU) { if (gen) FUSG_PICK(PK_ELU, true); else FUSG_PICK(PK_ELU, false); }
     else { if (gen) FUSG_PICK(PK_AFFINE, true); else FUSG_PICK(PK_AFFINE, false); }
 #undef FUSG_PICK
-    static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
-    if (!attr_done[pk][gen ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done[pk][gen ? 1 : 0] = true;
-    }
+    if (hipError_t e = ensure_dyn_lds(fn, (int)lds); e != hipSuccess) return e;
     ConvK kk = k;
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);

@@ -341,8 +341,7 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 32>;
     if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU) } else { FUSG_PICK_NI(PK_AFFINE) }
 #undef FUSG_PICK_NI
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) return e;
+    if (hipError_t e = ensure_dyn_lds(fn, 96 * 1024); e != hipSuccess) return e;
     HaloK kk = k;
     kk.RP = halo_row_pitch(k.HW, ch16);
     void* args[] = {(void*)&kk};

@@ -248,8 +248,7 @@ hipError_t launch_tapunit(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, i
     fn = unit == 8 ? (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 8> : (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 4>;
     if (pk == PK_NONE) { FUSG_PICK_U(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_U(PK_ELU) } else { FUSG_PICK_U(PK_AFFINE) }
 #undef FUSG_PICK_U
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e != hipSuccess) return e;
+    if (hipError_t e = ensure_dyn_lds(fn, 80 * 1024); e != hipSuccess) return e;
     TapUnitK kk = k;
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);

@@ -11,7 +11,7 @@
  * Conventions
  *  - extern "C", plain pointers and sizes.  No torch types.  All pointers are DEVICE pointers
  *    borrowed from the caller (e.g. tensor.data_ptr()); the library never allocates or frees
- *    caller-visible memory and keeps no mutable global state besides the opt-in profiler.
+ *    caller-visible memory and keeps no mutable state besides one-time per-device caches (kernel attributes, a 256-byte zero line) and the opt-in profiler.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call only enqueues
  *    work on that stream; nothing synchronises, so calls are graph-capturable.
  *  - Return 0 on success, negative fusg_status otherwise; fusg_last_error() gives a thread-local

@@ -350,17 +350,24 @@ def test_out_of_range_input_falls_back_to_exact_fp32(precision):
     vu = model("vunet")
     i = synth_inputs("vunet", 1, 128)
     y = i["y_tilde"].clone()
-    y[0, 1, 5, 5] = -7e4
+    y[0, 1, 5, 5] = 7e4                                           # (positive: the first conv stages ELU(y))
+    do, ds = vu.forward_dec_up(y.to(DEV))                         # flagged in its first conv -> redone in fp32
+    with ops.precision("f32"):
+        do32, ds32 = vu.forward_dec_up(y.to(DEV))
+    assert torch.equal(do[0], do32[0]) and len(ds) == 14 and all(torch.equal(a, b) for a, b in zip(ds, ds32))
+    # an entry point that consumes a list (`skips`) and CPU noise: poison its input so that the first pass is flagged
+    # half-way; the repeat must see the full list again and the same noise
+    do_bad = [do[0].clone()]
+    do_bad[0][0, 5, 1, 1] = 9e4
+    ds_a, ds_b = list(ds), list(ds)
     torch.manual_seed(3)
-    do, ds = vu.forward_dec_up(y.to(DEV))
-    n_skips = len(ds)
-    xt = vu.forward_dec_down(do, ds)[0]
-    assert ds == [] and n_skips == 14
+    xt = vu.forward_dec_down(do_bad, ds_a)[0]
+    assert ds_a == []
     with ops.precision("f32"):
         torch.manual_seed(3)
-        do2, ds2 = vu.forward_dec_up(y.to(DEV))
-        want = vu.forward_dec_down(do2, ds2)[0]
+        want = vu.forward_dec_down(do_bad, ds_b)[0]
     assert torch.equal(xt, want)
+    assert not ops.range_exceeded(DEV)
     # the pipeline checks a whole pass (per-network checks deferred) and redoes it in fp32
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
     pipe = VehiclePipeline(DEV)

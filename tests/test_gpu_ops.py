@@ -434,10 +434,11 @@ def test_f16x3_scale_sweep(name, cin, cout, k, pad, H, W, pre, family, precision
             ref = F.conv2d(xp, w.double(), b.double(), padding=pad)
             den = F.conv2d(xp.abs(), w.double().abs(), None, padding=pad) + 1e-300
             xin = _nhwc(x)
-            got3 = ops.conv(plan, xin, pre_op=pre, precision="f16x3")
+            ks = 0 if family == 1 else 1                      # (the halo / tap-unit kernels do not split K)
+            got3 = ops.conv(plan, xin, pre_op=pre, precision="f16x3", ksplit=ks)
             assert ops.last_conv_kernel() == family, (name, ops.last_conv_kernel())
             assert not ops.range_exceeded(dev())
-            got32 = ops.conv(plan, xin, pre_op=pre, precision="f32")
+            got32 = ops.conv(plan, xin, pre_op=pre, precision="f32", ksplit=ks)
             e3 = float(((got3.cpu().double() - ref).abs() / den).max())
             e32 = float(((got32.cpu().double() - ref).abs() / den).max())
             record("f16x3_err_max", e3)
@@ -459,17 +460,18 @@ def test_f16x3_out_of_range_raises_status(name, cin, cout, k, pad, H, W, pre, fa
     for bad in (1e5, -4e4, float("inf")):
         x = _rand(1, cin, H, W, seed=1)
         assert not ops.range_exceeded(dev())
-        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+        ks = 0 if family == 1 else 1
+        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3", ksplit=ks)
         assert not ops.range_exceeded(dev())                     # in range: status stays clear
         x[0, cin // 2, H // 2, W // 3] = bad
-        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+        ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3", ksplit=ks)
         assert ops.last_conv_kernel() == family
         assert ops.range_exceeded(dev())                         # raised (and cleared by the read)
         assert not ops.range_exceeded(dev())
     # just inside the range: exact handling, no flag
     x = _rand(1, cin, H, W, seed=1)
     x[0, 0, 0, 0] = 32767.0
-    got = ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3")
+    got = ops.conv(plan, _nhwc(x), pre_op=pre, precision="f16x3", ksplit=0 if family == 1 else 1)
     assert not ops.range_exceeded(dev())
     ref = F.conv2d({L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre].double(), w.double(), None, padding=pad)
     assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-6

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../future_urban_scene_generation_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
-for f in conv_halo_128 conv_halo_64 conv_halo_32 conv_halo_256x128 conv_halo_256x64; do
+for f in conv_halo_128 conv_halo_64 conv_halo_32; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off "$@" -c $f.hip -o $tmp/$f.o 2>$tmp/$f.log &
 done
 wait
