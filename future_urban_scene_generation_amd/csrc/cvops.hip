@@ -1,0 +1,394 @@
+// Device versions of the OpenCV-defined uint8 steps either side of the ICN (§8f-1, §8f-2):
+// perspective warp of the texture planes, polygon plane masks, ICN input assembly (crop -> resize -> Lab -> normalise)
+// and the way back (Lab -> BGR, resize-back + order-dependent masked paste).  The reference runs these on the host
+// through opencv-python (warp_learn/planes_utils.py:11-118, warp_learn/models.py:323-366,
+// trajectory_inference.py:184-198).  All of them are byte / integer work and HBM- or latency-bound: one thread per
+// output pixel, coalesced 3-byte stores, gathers served by L2; no matrix cores.  The arithmetic is OpenCV's published
+// 8-bit fixed-point algorithm for each op, restated independently in oracle/cv_host.py (parity unpinned: OpenCV is
+// absent from the build container, see that file's header).
+#include <math.h>
+#include <mutex>
+#include "common.h"
+
+namespace fusg {
+
+struct U8View { unsigned char* p; long sn, sh, sw; int n, h, w; };
+static inline bool is_u8_hwc(const fusg_tensor& t, int c) {
+    return t.data && t.dtype == FUSG_U8 && t.c == c && t.sc == 1 && t.sw >= c && t.sh >= t.w * t.sw && t.n >= 1 && t.h >= 1 && t.w >= 1 &&
+           t.h < 32768 && t.w < 32768;
+}
+static inline U8View u8view(const fusg_tensor& t) {
+    return U8View{(unsigned char*)t.data, t.sn, t.sh, t.sw, (int)t.n, (int)t.h, (int)t.w};
+}
+static inline unsigned blocks2d(long total) { return (unsigned)((total + 255) / 256); }
+
+// ------------------------------------------------------------------------------------------------ warpPerspective
+// dst(x, y) = bilinear(src, Minv * (x, y, 1)): coordinates in double, rounded to 1/32 pixel (INTER_BITS = 5), weights
+// (32-ax)(32-ay)*32 ... in 15-bit fixed point (table entry (0,0) is (32767, 0, 0, 1): imgwarp.cpp initInterTab2D),
+// (sum + 2^14) >> 15, constant border 0.
+__global__ __launch_bounds__(256) void warp_perspective_u8_kernel(U8View src, const double* __restrict__ minv, U8View dst, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % dst.w);
+    const long r = idx / dst.w;
+    const int y = (int)(r % dst.h);
+    const int n = (int)(r / dst.h);
+    const double* M = minv + (long)n * 9;
+    const double X0 = M[0] * x + M[1] * y + M[2];
+    const double Y0 = M[3] * x + M[4] * y + M[5];
+    const double W0 = M[6] * x + M[7] * y + M[8];
+    const double W = W0 != 0.0 ? 32.0 / W0 : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+    const long X = (long)rint(fX), Y = (long)rint(fY);                  // cvRound: to nearest, ties to even
+    long sx = X >> 5, sy = Y >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const int ax = (int)(X & 31), ay = (int)(Y & 31);
+    int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+    if ((ax | ay) == 0) { w00 = 32767; w11 = 1; }
+    const unsigned char* s = src.p + (long)n * src.sn;
+    const bool y0ok = sy >= 0 && sy < src.h, y1ok = sy + 1 >= 0 && sy + 1 < src.h;
+    const bool x0ok = sx >= 0 && sx < src.w, x1ok = sx + 1 >= 0 && sx + 1 < src.w;
+    const unsigned char* p00 = s + sy * src.sh + sx * src.sw;
+    unsigned char* d = dst.p + (long)n * dst.sn + (long)y * dst.sh + (long)x * dst.sw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int v00 = (y0ok && x0ok) ? p00[c] : 0, v01 = (y0ok && x1ok) ? p00[src.sw + c] : 0;
+        const int v10 = (y1ok && x0ok) ? p00[src.sh + c] : 0, v11 = (y1ok && x1ok) ? p00[src.sh + src.sw + c] : 0;
+        const int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        const int o = (acc + (1 << 14)) >> 15;
+        d[c] = (unsigned char)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fillPoly planes
+// dst[p](y, x, :) = frame(y, x, :) * inside_or_on_outline(polygon p): cv::fillPoly at shift 0 = the 8-connected outline
+// drawn left to right (LineIterator) + the even-odd scanline interior with 16.16 fixed-point edge crossings,
+// x1 = ceil(crossing), x2 = floor(next crossing) (drawing.cpp CollectPolyEdges / FillEdgeCollection).
+constexpr int MAXV = 8;
+struct PolySet { int nv[8]; int px[8][MAXV]; int py[8][MAXV]; };
+
+__device__ __forceinline__ bool on_line(int x, int y, int x0, int y0, int x1, int y1) {
+    if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+    const int dx = x1 - x0, dyv = y1 - y0, dy = dyv < 0 ? -dyv : dyv, sy = dyv >= 0 ? 1 : -1;
+    if (dx >= dy) {
+        const int k = x - x0;
+        if (k < 0 || k > dx) return false;
+        const int yy = y0 + sy * (dx ? (int)((2L * dy * k + dx - 1) / (2L * dx)) : 0);
+        return yy == y;
+    }
+    const int k = (y - y0) * sy;
+    if (k < 0 || k > dy) return false;
+    return x0 + (int)((2L * dx * k + dy - 1) / (2L * dy)) == x;
+}
+
+__global__ __launch_bounds__(256) void fill_poly_planes_kernel(U8View frame, PolySet ps, U8View dst, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % dst.w);
+    const long r = idx / dst.w;
+    const int y = (int)(r % dst.h);
+    const int p = (int)(r / dst.h);
+    const int nv = ps.nv[p];
+    bool in = false;
+    long xs[MAXV];
+    int nx = 0;
+    for (int i = 0; i < nv; ++i) {
+        const int j = i == 0 ? nv - 1 : i - 1;
+        const int ax = ps.px[p][j], ay = ps.py[p][j], bx = ps.px[p][i], by = ps.py[p][i];
+        in = in || on_line(x, y, ax, ay, bx, by);
+        if (ay == by) continue;
+        const int y0 = ay < by ? ay : by, y1 = ay < by ? by : ay, xa = ay < by ? ax : bx;
+        if (y < y0 || y >= y1) continue;
+        const long num = ((long)bx - ax) << 16, den = (long)by - ay;
+        const long dxf = num / den;                                    // C++ integer division truncates toward zero
+        const long xc = ((long)xa << 16) + dxf * (y - y0);
+        int k = nx++;
+        while (k > 0 && xs[k - 1] > xc) { xs[k] = xs[k - 1]; --k; }   // insertion sort (<= 8 crossings)
+        xs[k] = xc;
+    }
+    for (int k = 0; k + 1 < nx; k += 2) {
+        const long x1 = (xs[k] + 65535) >> 16, x2 = xs[k + 1] >> 16;
+        in = in || (x >= x1 && x <= x2);
+    }
+    const unsigned char* s = frame.p + (long)y * frame.sh + (long)x * frame.sw;
+    unsigned char* d = dst.p + (long)p * dst.sn + (long)y * dst.sh + (long)x * dst.sw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = in ? s[c] : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ resize + Lab
+// cv::resize INTER_LINEAR, uint8: source index / 11-bit weights of one destination coordinate (float arithmetic as in
+// resize.cpp), horizontal pass in int, vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+__device__ __forceinline__ void resize_coef(int d, int ssize, int dsize, int& s, int& a0, int& a1) {
+    const double scale = (double)ssize / dsize;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
+    s = si;
+    a0 = (int)rintf((1.f - f) * 2048.f);
+    a1 = (int)rintf(f * 2048.f);
+}
+
+struct LabTabs { const unsigned short* gamma; const unsigned short* cbrt; int coef[9]; };
+
+// one pixel RGB (or BGR) uint8 -> Lab uint8, OpenCV's integer path (color_lab.cpp RGB2Lab_b)
+__device__ __forceinline__ void rgb2lab_px(const LabTabs& t, int r, int g, int b, int& L, int& A, int& B) {
+    const int R = t.gamma[r], G = t.gamma[g], Bc = t.gamma[b];
+    const int fX = t.cbrt[(R * t.coef[0] + G * t.coef[1] + Bc * t.coef[2] + (1 << 11)) >> 12];
+    const int fY = t.cbrt[(R * t.coef[3] + G * t.coef[4] + Bc * t.coef[5] + (1 << 11)) >> 12];
+    const int fZ = t.cbrt[(R * t.coef[6] + G * t.coef[7] + Bc * t.coef[8] + (1 << 11)) >> 12];
+    const int Lscale = (116 * 255 + 50) / 100, Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    L = (Lscale * fY + Lshift + (1 << 14)) >> 15;
+    A = (500 * (fX - fY) + 128 * (1 << 15) + (1 << 14)) >> 15;
+    B = (200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15;
+    L = L < 0 ? 0 : (L > 255 ? 255 : L); A = A < 0 ? 0 : (A > 255 ? 255 : A); B = B < 0 ? 0 : (B > 255 ? 255 : B);
+}
+
+// per-device Lab tables: gamma[256], cbrt[3072] (ushort), built once on the host with OpenCV's formulas
+static const unsigned short* lab_tables_dev(int coef[9]) {
+    static std::mutex mu;
+    static unsigned short* tabs[64] = {};
+    static int coef_h[9];
+    static bool coef_done = false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!coef_done) {
+        const double m[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+        const double wp[3] = {0.950456, 1.0, 1.088754};
+        for (int i = 0; i < 9; ++i) coef_h[i] = (int)rint(4096.0 * m[i] / wp[i / 3]);
+        coef_done = true;
+    }
+    for (int i = 0; i < 9; ++i) coef[i] = coef_h[i];
+    if (!tabs[dev]) {
+        static unsigned short host[256 + 3072];
+        for (int i = 0; i < 256; ++i) {
+            const float x = (float)i * (1.f / 255.f);
+            const float v = x <= 0.04045f ? x * (1.f / 12.92f) : (float)pow(((double)x + 0.055) * (1. / 1.055), 2.4);
+            const float q = rintf(255.f * 8.f * v);
+            host[i] = (unsigned short)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : q));
+        }
+        for (int i = 0; i < 3072; ++i) {
+            const float x = (float)i * (1.f / (255.f * 8.f));
+            const float v = x < 0.008856f ? x * 7.787f + 0.13793103448275862f : (float)cbrt((double)x);   // (OpenCV: cvCbrt, a fast approximation)
+            const float q = rintf(32768.f * v);
+            host[256 + i] = (unsigned short)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : q));
+        }
+        unsigned short* q = nullptr;
+        if (hipMalloc((void**)&q, sizeof(host)) != hipSuccess) return nullptr;
+        if (hipMemcpy(q, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(q); return nullptr; }
+        tabs[dev] = q;
+    }
+    return tabs[dev];
+}
+
+// ICN input assembly for a batch of vehicles.  Per vehicle b: `nimg` images (sketch, then the planes) of the same
+// frame size are cropped to the square window geom[b] = (x0, y0, x1, y1, pad_x_before, pad_y_before) of the
+// zero-padded frame (utils/crop_utils.py:27-50), resized to out_h x out_w, converted to Lab and written as
+// (lab/255 - 0.5)/0.5 into channels [3*slot(i), +3) of dst[b] (slot 0 = sketch, slot 1 = central crop, slots 2.. =
+// planes).  The central crop (already out_h x out_w) skips crop and resize.
+struct IcnIn {
+    U8View sketch, central, planes;      // sketch [B], central [B], planes [B * nplanes]
+    const int* geom;                     // [B][8]
+    float* dst; long dsn, dsh, dsw;      // NHWC-physical f32
+    int B, out_h, out_w, nplanes;
+    LabTabs t;
+};
+
+__device__ __forceinline__ int crop_fetch(const unsigned char* img, const U8View& v, int px, int py, int c) {
+    // pixel (px, py) of the un-padded frame, 0 in the padding
+    return ((unsigned)px < (unsigned)v.w && (unsigned)py < (unsigned)v.h) ? img[(long)py * v.sh + (long)px * v.sw + c] : 0;
+}
+
+__global__ __launch_bounds__(256) void icn_inputs_kernel(IcnIn a, long total) {
+    __shared__ unsigned short s_gamma[256];
+    __shared__ unsigned short s_cbrt[3072];
+    for (int i = threadIdx.x; i < 256; i += 256) s_gamma[i] = a.t.gamma[i];
+    for (int i = threadIdx.x; i < 3072; i += 256) s_cbrt[i] = a.t.cbrt[i];
+    __syncthreads();
+    LabTabs t = a.t;
+    t.gamma = s_gamma; t.cbrt = s_cbrt;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.out_w);
+    long r = idx / a.out_w;
+    const int y = (int)(r % a.out_h);
+    r /= a.out_h;
+    const int slot = (int)(r % (a.nplanes + 2));
+    const int b = (int)(r / (a.nplanes + 2));
+    int rgb[3];
+    if (slot == 1) {
+        const unsigned char* s = a.central.p + (long)b * a.central.sn + (long)y * a.central.sh + (long)x * a.central.sw;
+        rgb[0] = s[0]; rgb[1] = s[1]; rgb[2] = s[2];
+    } else {
+        const U8View& v = slot == 0 ? a.sketch : a.planes;
+        const unsigned char* img = v.p + (slot == 0 ? (long)b : (long)b * a.nplanes + (slot - 2)) * v.sn;
+        const int* g = a.geom + b * 8;
+        const int cw = g[2] - g[0], ch = g[3] - g[1];
+        const int ox = g[0] - g[4], oy = g[1] - g[5];                  // crop origin in un-padded frame coordinates
+        if (cw == a.out_w && ch == a.out_h) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = crop_fetch(img, v, ox + x, oy + y, c);
+        } else {
+            int sx, ax0, ax1, sy, ay0, ay1;
+            resize_coef(x, cw, a.out_w, sx, ax0, ax1);
+            resize_coef(y, ch, a.out_h, sy, ay0, ay1);
+            const int sx1 = sx + 1 < cw ? sx + 1 : cw - 1, sy1 = sy + 1 < ch ? sy + 1 : ch - 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int S0 = crop_fetch(img, v, ox + sx, oy + sy, c) * ax0 + crop_fetch(img, v, ox + sx1, oy + sy, c) * ax1;
+                const int S1 = crop_fetch(img, v, ox + sx, oy + sy1, c) * ax0 + crop_fetch(img, v, ox + sx1, oy + sy1, c) * ax1;
+                const int o = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                rgb[c] = o < 0 ? 0 : (o > 255 ? 255 : o);
+            }
+        }
+    }
+    int L, A, Bv;
+    if (slot >= 2) rgb2lab_px(t, rgb[2], rgb[1], rgb[0], L, A, Bv);     // planes are BGR (planes_utils.py:88)
+    else rgb2lab_px(t, rgb[0], rgb[1], rgb[2], L, A, Bv);               // sketch / central crop are RGB (models.py:355,358)
+    float* d = a.dst + (long)b * a.dsn + (long)y * a.dsh + (long)x * a.dsw + slot * 3;
+    d[0] = ((float)L / 255.f - 0.5f) / 0.5f;
+    d[1] = ((float)A / 255.f - 0.5f) / 0.5f;
+    d[2] = ((float)Bv / 255.f - 0.5f) / 0.5f;
+}
+
+// ------------------------------------------------------------------------------------------------ Lab -> BGR
+__device__ __forceinline__ float lab_finv(float f) { return f <= (6.f / 29.f) ? (f - 16.f / 116.f) / 7.787f : f * f * f; }
+__device__ __forceinline__ float srgb_gamma(float v) {
+    return v <= 0.0031308f ? v * 12.92f : 1.055f * (float)pow((double)v, 1.0 / 2.4) - 0.055f;
+}
+__global__ __launch_bounds__(256) void lab2bgr_u8_kernel(U8View src, U8View dst, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % dst.w);
+    const long r = idx / dst.w;
+    const int y = (int)(r % dst.h);
+    const int n = (int)(r / dst.h);
+    const unsigned char* s = src.p + (long)n * src.sn + (long)y * src.sh + (long)x * src.sw;
+    const float L = (float)s[0] * (100.f / 255.f), a = (float)s[1] - 128.f, b = (float)s[2] - 128.f;
+    float fy = (L + 16.f) / 116.f, Y;
+    if (L <= 903.3f * 0.008856f) { Y = L / 903.3f; fy = 7.787f * Y + 16.f / 116.f; } else Y = fy * fy * fy;
+    const float X = lab_finv(fy + a / 500.f) * 0.950456f, Z = lab_finv(fy - b / 200.f) * 1.088754f;
+    float R = 3.240479f * X + -1.53715f * Y + -0.498535f * Z;
+    float G = -0.969256f * X + 1.875991f * Y + 0.041556f * Z;
+    float Bl = 0.055648f * X + -0.204043f * Y + 1.057311f * Z;
+    R = fminf(fmaxf(R, 0.f), 1.f); G = fminf(fmaxf(G, 0.f), 1.f); Bl = fminf(fmaxf(Bl, 0.f), 1.f);
+    unsigned char* d = dst.p + (long)n * dst.sn + (long)y * dst.sh + (long)x * dst.sw;
+    const float o[3] = {srgb_gamma(Bl) * 255.f, srgb_gamma(G) * 255.f, srgb_gamma(R) * 255.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float q = rintf(o[c]); d[c] = (unsigned char)(q < 0.f ? 0.f : (q > 255.f ? 255.f : q)); }
+}
+
+// ------------------------------------------------------------------------------------------------ paste back
+// frame(y, x) <- for the LAST vehicle v (in index order) whose paste mask covers (y, x): the pixel of vehicle v's
+// network image resized back to its crop (cv::resize INTER_LINEAR), with the crop padding removed and placed at
+// crop_xy_min - or 0 where the pixel lies outside that rectangle (the reference pastes from a zero canvas,
+// trajectory_inference.py:190-198); pixels no mask covers keep the frame's value.
+struct PasteIn { U8View net; U8View masks; U8View frame; const int* geom; int V; };   // geom [V][8] as in IcnIn
+__global__ __launch_bounds__(256) void paste_back_kernel(PasteIn a, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.frame.w), y = (int)(idx / a.frame.w);
+    for (int v = a.V - 1; v >= 0; --v) {
+        if (!a.masks.p[(long)v * a.masks.sn + (long)y * a.masks.sh + (long)x * a.masks.sw]) continue;
+        const int* g = a.geom + v * 8;
+        const int cw = g[2] - g[0], ch = g[3] - g[1];
+        // canvas rectangle: starts at crop_xy_min = (x0, y0); holds crop pixels [pad_before, size - pad_after)
+        const int cx = x - g[0] + g[4], cy = y - g[1] + g[5];
+        const int xa = g[6], ya = g[7];
+        unsigned char* d = a.frame.p + (long)y * a.frame.sh + (long)x * a.frame.sw;
+        const bool inside = cx >= g[4] && cy >= g[5] && cx < cw - xa && cy < ch - ya;
+        if (!inside) { d[0] = 0; d[1] = 0; d[2] = 0; return; }
+        const unsigned char* img = a.net.p + (long)v * a.net.sn;
+        if (cw == a.net.w && ch == a.net.h) {
+            const unsigned char* s = img + (long)cy * a.net.sh + (long)cx * a.net.sw;
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+            return;
+        }
+        int sx, ax0, ax1, sy, ay0, ay1;
+        resize_coef(cx, a.net.w, cw, sx, ax0, ax1);
+        resize_coef(cy, a.net.h, ch, sy, ay0, ay1);
+        const int sx1 = sx + 1 < a.net.w ? sx + 1 : a.net.w - 1, sy1 = sy + 1 < a.net.h ? sy + 1 : a.net.h - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int S0 = img[(long)sy * a.net.sh + (long)sx * a.net.sw + c] * ax0 + img[(long)sy * a.net.sh + (long)sx1 * a.net.sw + c] * ax1;
+            const int S1 = img[(long)sy1 * a.net.sh + (long)sx * a.net.sw + c] * ax0 + img[(long)sy1 * a.net.sh + (long)sx1 * a.net.sw + c] * ax1;
+            const int o = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            d[c] = (unsigned char)(o < 0 ? 0 : (o > 255 ? 255 : o));
+        }
+        return;
+    }
+}
+
+}  // namespace fusg
+
+using namespace fusg;
+
+extern "C" int fusg_warp_perspective_u8(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream) {
+    FUSG_CHECK(src && dst && minv && is_u8_hwc(*src, 3) && is_u8_hwc(*dst, 3) && src->n == dst->n, "warp_perspective_u8: u8 HWC tensors of 3 channels, same n");
+    FUSG_CHECK(src->data != dst->data, "warp_perspective_u8: in-place not supported");
+    const long total = dst->n * dst->h * dst->w;
+    hipLaunchKernelGGL(warp_perspective_u8_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, u8view(*src), minv, u8view(*dst), total);
+    FUSG_LAUNCH_CHECK("warp_perspective_u8");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_fill_poly_planes_u8(const fusg_tensor* frame, const int32_t* pts_xy, const int32_t* nverts, int32_t nplanes,
+                                        const fusg_tensor* dst, void* stream) {
+    FUSG_CHECK(frame && dst && pts_xy && nverts && is_u8_hwc(*frame, 3) && is_u8_hwc(*dst, 3) && frame->n == 1 && dst->n == nplanes &&
+               nplanes >= 1 && nplanes <= 8 && frame->h == dst->h && frame->w == dst->w, "fill_poly_planes_u8: shapes (<= 8 planes)");
+    PolySet ps;
+    memset(&ps, 0, sizeof(ps));
+    for (int p = 0; p < nplanes; ++p) {                                  // HOST arrays: [nplanes][MAXV][2], [nplanes]
+        FUSG_CHECK(nverts[p] >= 0 && nverts[p] <= MAXV, "fill_poly_planes_u8: %d vertices (max %d)", nverts[p], MAXV);
+        ps.nv[p] = nverts[p];
+        for (int i = 0; i < nverts[p]; ++i) { ps.px[p][i] = pts_xy[(p * MAXV + i) * 2]; ps.py[p][i] = pts_xy[(p * MAXV + i) * 2 + 1]; }
+    }
+    const long total = dst->n * dst->h * dst->w;
+    hipLaunchKernelGGL(fill_poly_planes_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, u8view(*frame), ps, u8view(*dst), total);
+    FUSG_LAUNCH_CHECK("fill_poly_planes_u8");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_icn_inputs(const fusg_tensor* sketch, const fusg_tensor* central, const fusg_tensor* planes, const int32_t* geom,
+                               const fusg_tensor* dst, void* stream) {
+    FUSG_CHECK(sketch && central && planes && geom && dst && is_u8_hwc(*sketch, 3) && is_u8_hwc(*central, 3) && is_u8_hwc(*planes, 3),
+               "icn_inputs: u8 HWC inputs");
+    FUSG_CHECK(is_nhwc(*dst) && dst->n == sketch->n && central->n == sketch->n && planes->n % sketch->n == 0 && planes->n / sketch->n >= 1 &&
+               planes->n / sketch->n <= 6 && planes->h == sketch->h && planes->w == sketch->w && central->h == dst->h && central->w == dst->w &&
+               dst->c == 3 * (planes->n / sketch->n + 2), "icn_inputs: shapes");
+    IcnIn a;
+    a.sketch = u8view(*sketch); a.central = u8view(*central); a.planes = u8view(*planes);
+    a.geom = geom; a.dst = (float*)dst->data; a.dsn = dst->sn; a.dsh = dst->sh; a.dsw = dst->sw;
+    a.B = (int)sketch->n; a.out_h = (int)dst->h; a.out_w = (int)dst->w; a.nplanes = (int)(planes->n / sketch->n);
+    const unsigned short* tabs = lab_tables_dev(a.t.coef);
+    if (!tabs) { set_error("icn_inputs: cannot build the Lab tables"); return FUSG_ERR_LAUNCH; }
+    a.t.gamma = tabs; a.t.cbrt = tabs + 256;
+    const long total = (long)a.B * (a.nplanes + 2) * a.out_h * a.out_w;
+    hipLaunchKernelGGL(icn_inputs_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, a, total);
+    FUSG_LAUNCH_CHECK("icn_inputs");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream) {
+    FUSG_CHECK(src && dst && is_u8_hwc(*src, 3) && is_u8_hwc(*dst, 3) && src->n == dst->n && src->h == dst->h && src->w == dst->w, "lab2bgr_u8: shapes");
+    const long total = dst->n * dst->h * dst->w;
+    hipLaunchKernelGGL(lab2bgr_u8_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, u8view(*src), u8view(*dst), total);
+    FUSG_LAUNCH_CHECK("lab2bgr_u8");
+    return FUSG_OK;
+}
+
+extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) {
+    FUSG_CHECK(net && masks && geom && frame && is_u8_hwc(*net, 3) && is_u8_hwc(*frame, 3) && frame->n == 1 && masks->data &&
+               masks->dtype == FUSG_U8 && masks->c == 1 && masks->n == net->n && masks->h == frame->h && masks->w == frame->w, "paste_back_u8: shapes");
+    PasteIn a;
+    a.net = u8view(*net); a.masks = u8view(*masks); a.frame = u8view(*frame); a.geom = geom; a.V = (int)net->n;
+    const long total = frame->h * frame->w;
+    hipLaunchKernelGGL(paste_back_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, a, total);
+    FUSG_LAUNCH_CHECK("paste_back_u8");
+    return FUSG_OK;
+}

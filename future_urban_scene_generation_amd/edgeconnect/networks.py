@@ -132,3 +132,15 @@ class InpaintGenerator(_Generator):
 class EdgeGenerator(_Generator):
     def __init__(self, residual_blocks=8, use_spectral_norm=True, init_weights=True):
         super().__init__(3, 1, residual_blocks, spectral=use_spectral_norm, final_act=L.ACT_SIGMOID)
+
+
+class Discriminator(nn.Module):
+    """Name kept importable for `from edgeconnect.networks import InpaintGenerator, EdgeGenerator, Discriminator`
+    (reference edgeconnect/models.py:5).  The PatchGAN discriminator (reference networks.py:138-181) is used only by
+    the training half of EdgeModel / InpaintingModel (models.py:62, 154: adversarial loss), which is outside the
+    inference hot path: constructing it here is an error rather than a silent CPU module."""
+
+    def __init__(self, in_channels, use_sigmoid=True, use_spectral_norm=True, init_weights=True):
+        super().__init__()
+        raise NotImplementedError("edgeconnect.networks.Discriminator belongs to EdgeConnect's training half, which the "
+                                  "MI355X inference path does not provide (SURVEY.md §2 row 8)")

@@ -184,33 +184,9 @@ class G_Resnet(FusedNet):
 
 
 def get_icn_inputs(planes, sketch_normal, sketch_mask, central_crop, icn_w: int, icn_h: int):
-    """Host-side ICN input assembly (reference warp_learn/models.py:323-366): crop all inputs to the
-    1.1x square box around the sketch mask, resize to (icn_w, icn_h), convert to LAB, scale to [-1, 1]
-    and stack [sketch(3), central crop(3), planes(5x3)] -> float32 [1, 21, icn_h, icn_w] + crop_info.
-
-    This step is OpenCV arithmetic (`cv2.resize`, `cv2.cvtColor(..., COLOR_*2LAB)`); OpenCV is not
-    available in the build container, so its parity is UNPINNED and it stays on the
-    host.  It needs `cv2` and the reference's `utils.crop_utils` on the path at call time."""
-    import numpy as np
-    try:
-        import cv2
-        from utils.crop_utils import square_crop_from_bbox
-    except ImportError as e:                                   # pragma: no cover
-        raise ImportError("get_icn_inputs needs OpenCV and the reference's utils.crop_utils on sys.path") from e
-
-    ys, xs = np.nonzero(sketch_mask)
-    box = [np.min(xs), np.min(ys), np.max(xs), np.max(ys)]
-    crop, xy_min, pad_before, pad_after, _, _ = square_crop_from_bbox(sketch_normal, box)
-    crop_info = {"crop_xy_min": xy_min, "pad_xy_before": pad_before, "pad_xy_after": pad_after,
-                 "crop_size_orig": crop.shape[:2]}
-
-    def lab_pm1(img_u8, code):
-        lab = cv2.cvtColor(img_u8, code).astype(np.float32) / 255.0
-        return torch.from_numpy(np.ascontiguousarray(lab.transpose(2, 0, 1))).sub_(0.5).div_(0.5)
-
-    parts = [lab_pm1(cv2.resize(crop, (icn_w, icn_h)), cv2.COLOR_RGB2LAB),
-             lab_pm1(central_crop, cv2.COLOR_RGB2LAB)]
-    for i in range(len(planes)):
-        pl = cv2.resize(square_crop_from_bbox(planes[i], box)[0], (icn_w, icn_h))
-        parts.append(lab_pm1(pl, cv2.COLOR_BGR2LAB))
-    return torch.cat(parts, dim=0).unsqueeze(0), crop_info
+    """ICN input assembly (reference warp_learn/models.py:323-366): crop all inputs to the 1.1x square box around the
+    sketch mask, resize to (icn_w, icn_h), convert to Lab, scale to [-1, 1] and stack [sketch(3), central crop(3),
+    planes(5x3)] -> float32 [1, 21, icn_h, icn_w] + crop_info.  Runs on the device (one libfusg launch,
+    planes_utils.get_icn_inputs); numpy or CUDA uint8 images are accepted.  OpenCV arithmetic, parity unpinned."""
+    from .planes_utils import get_icn_inputs as _impl
+    return _impl(planes, sketch_normal, sketch_mask, central_crop, icn_w, icn_h)

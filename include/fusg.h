@@ -253,6 +253,34 @@ int fusg_to_image_u8(const fusg_tensor* x, const fusg_tensor* dst, void* stream)
 int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_tensor* mask,
                   const fusg_tensor* dst, void* stream);
 
+/* ---- OpenCV-defined uint8 steps around the ICN (device versions; parity unpinned, see oracle/cv_host.py) ------- */
+/* U8 images are fusg_tensors with dtype FUSG_U8, logical [n, 3, h, w] and HWC strides (sc = 1, sw >= 3).           */
+
+/* cv2.warpPerspective(src, H, dsize=(w, h)) with INTER_LINEAR / BORDER_CONSTANT 0 (warp_learn/planes_utils.py:76-77)
+ * for n images at once: minv = n row-major 3x3 DOUBLE matrices in DEVICE memory, each the INVERSE of that image's H
+ * (OpenCV inverts H on the host too).  Coordinates in double, rounded to 1/32 pixel, 15-bit bilinear weights,
+ * (sum + 2^14) >> 15.  src and dst may differ in h, w. */
+int fusg_warp_perspective_u8(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream);
+/* get_planes (warp_learn/planes_utils.py:11-37): dst[p] = frame * fillPoly(polygon p) for up to 8 polygons of up
+ * to 8 int32 vertices.  pts_xy [nplanes][8][2] (x, y) and nverts [nplanes] are HOST arrays (read before return). */
+int fusg_fill_poly_planes_u8(const fusg_tensor* frame, const int32_t* pts_xy, const int32_t* nverts, int32_t nplanes,
+                             const fusg_tensor* dst, void* stream);
+/* get_icn_inputs (warp_learn/models.py:323-366) for a batch of B vehicles: sketch [B] (RGB), central [B] (RGB, already
+ * dst.h x dst.w), planes [B * P] (BGR, P <= 6, same frame size as sketch); geom = DEVICE int32 [B][8] =
+ * (x0, y0, x1, y1, pad_x_before, pad_y_before, pad_x_after, pad_y_after) of square_crop_from_bbox
+ * (utils/crop_utils.py:27-50).  Crop of the zero-padded frame -> cv2.resize INTER_LINEAR -> RGB/BGR2LAB (8-bit integer
+ * path) -> (v/255 - 0.5)/0.5, written to dst f32 NHWC-physical [B, 3 * (P + 2), h, w] in the reference's channel
+ * order (sketch, central, planes). */
+int fusg_icn_inputs(const fusg_tensor* sketch, const fusg_tensor* central, const fusg_tensor* planes, const int32_t* geom,
+                    const fusg_tensor* dst, void* stream);
+/* cv2.cvtColor(x, COLOR_LAB2BGR) on uint8 (to_image(from_LAB=True), warp_learn/planes_utils.py:117). */
+int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream);
+/* Resize-back + order-dependent masked paste (trajectory_inference.py:184-198) of V network images net [V] (u8,
+ * e.g. 256 x 256) into ONE frame: a frame pixel covered by paste masks takes, from the LAST covering vehicle, that
+ * vehicle's image resized (cv2.resize INTER_LINEAR) to its crop, padding removed, placed at crop_xy_min - or 0 where
+ * the pixel lies outside that rectangle; masks u8 [V, 1, H, W] (non-zero = paste), geom as in fusg_icn_inputs. */
+int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream);
+
 /* ---- misc ----------------------------------------------------------------------------------- */
 
 int         fusg_version(void);

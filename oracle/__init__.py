@@ -18,9 +18,13 @@ Parity pin: tools/gen_golden.py imports the *reference* modules in the build con
 synthetic weights of ``future_urban_scene_generation_amd.synth`` into them and writes their
 outputs to ``tests/golden/*.npz``.  ``tests/test_oracle_golden.py`` checks every oracle function
 against those vectors (bit-exact on the generating machine, <=1e-5 elsewhere because oneDNN picks
-different blockings on different CPUs).  The OpenCV/Open3D/scikit-image host steps of the
-reference (homography warp, LAB conversion, resize, Canny) are NOT restated here: those packages
-are absent from the build container, so parity for them is unpinned.
+different blockings on different CPUs).
+
+PARITY UNPINNED for ``oracle/cv_host.py``: the OpenCV-defined host steps of the reference (homography warp,
+fillPoly masks, resize, Lab conversion, findHomography) are restated there from OpenCV's published 8-bit
+algorithms, because opencv-python is un-vendored, unpinned (requirements.txt:5) and absent from the build
+container, and the reference holds no fixtures for them.  The scikit-image Canny and Open3D
+rendering steps are not restated at all.
 """
 from .hourglass import hourglass_forward, heatmap_argmax, get_maxima          # noqa: F401
 from .icn import icn_forward                                                  # noqa: F401
@@ -30,3 +34,4 @@ from .edgeconnect import (edge_generator_forward, inpaint_generator_forward,  # 
                           edge_model_forward, inpaint_model_forward)
 from .host import to_image_u8, to_tensor_pm1, ssim                            # noqa: F401
 from .pipeline import crop_pass                                               # noqa: F401
+from . import cv_host                                                         # noqa: F401

@@ -1,0 +1,54 @@
+"""The PYTHONPATH route of INTEGRATION.md §2: with dropin/ in front of a reference checkout, the reference's own import
+statements (run_test.py:13-21, trajectory_inference.py:26-29, edgeconnect/models.py:5) resolve to the MI355X modules,
+while the reference's other sub-modules of the merged packages keep resolving to the checkout.  CPU only: imports,
+constructors and state_dict schemas (no forward)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
+    # a stand-in for the reference checkout: only the sibling modules the merged packages must keep finding
+    ref = tmp_path / "reference"
+    for pkg, mod in (("warp_learn", "planes_utils"), ("warp_learn", "online_visibility"), ("edgeconnect", "config"),
+                     ("edgeconnect", "utils")):
+        d = ref / pkg
+        d.mkdir(parents=True, exist_ok=True)
+        (d / "__init__.py").write_text("")
+        (d / f"{mod}.py").write_text(f"MARKER = 'reference {pkg}.{mod}'\n")
+    (ref / "vunet").mkdir()                                    # the reference's vunet/ has no __init__.py
+    (ref / "vunet" / "data_utils.py").write_text("MARKER = 'reference vunet.data_utils'\n")
+    code = textwrap.dedent("""
+        import json
+        from argparse import Namespace
+        from stacked_hourglass.models import HourglassNet                      # run_test.py:15
+        from warp_learn.models import G_Resnet, get_icn_inputs                 # run_test.py:21, trajectory_inference.py:26
+        from vunet.models import Vunet_fix_res                                 # run_test.py:20
+        from edgeconnect.models import EdgeModel, InpaintingModel              # run_test.py:13-14
+        from edgeconnect.networks import InpaintGenerator, EdgeGenerator, Discriminator   # edgeconnect/models.py:5
+        import warp_learn.planes_utils, warp_learn.online_visibility, edgeconnect.config, edgeconnect.utils
+        import vunet.data_utils
+        from future_urban_scene_generation_amd.pipeline import load_schema
+        from future_urban_scene_generation_amd.synth import schema_of
+        nets = {"hg": HourglassNet(num_stacks=2, num_blocks=1, num_classes=12), "icn": G_Resnet(21),
+                "vunet": Vunet_fix_res(Namespace(up_mode="subpixel", w_norm=True, drop_prob=0.2, vunet_256=True)),
+                "edge": EdgeModel(None).generator, "inpaint": InpaintingModel(None).generator}
+        out = {"modules": {k: type(v).__module__ for k, v in nets.items()},
+               "schema_ok": {k: list(schema_of(v.state_dict()).items()) == list(load_schema(k).items()) for k, v in nets.items()},
+               "siblings": [warp_learn.planes_utils.MARKER, warp_learn.online_visibility.MARKER, edgeconnect.config.MARKER,
+                            edgeconnect.utils.MARKER, vunet.data_utils.MARKER],
+               "to_str": str(next(nets["hg"].to("cpu").parameters()).device)}
+        print("RESULT " + json.dumps(out))
+    """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(REPO, "dropin"), REPO, str(ref)]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert all(m.startswith("future_urban_scene_generation_amd.") for m in out["modules"].values()), out["modules"]
+    assert all(out["schema_ok"].values()), out["schema_ok"]
+    assert out["siblings"] == ["reference warp_learn.planes_utils", "reference warp_learn.online_visibility",
+                               "reference edgeconnect.config", "reference edgeconnect.utils", "reference vunet.data_utils"]
