@@ -243,12 +243,15 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         default: break;
     }
     const bool gen = d->pad_mode != FUSG_PAD_ZERO || d->upsample != 0;
-    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->upsample + d->stride <= 2 && d->ksplit <= 1 &&
+    // halo kernel: stride 1 (any dilation / padding mode / fused upsample), or stride 2 in parity-quadrant form
+    // (wfrag_order 1: k3/k4, pad 1, one source, even H and W); everything else takes the generic gather
+    const bool s2d_form = d->wfrag_order == 1 && d->stride == 2 && x0.h % 2 == 0 && x0.w % 2 == 0;
+    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->ksplit <= 1 &&
+                         ((d->stride == 1 && d->wfrag_order == 0) || (s2d_form && d->upsample == 0)) &&
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
-                         !env_switches().no_halo && (d->q_oy | d->q_ox) == 0 && d->wfrag_order != 2 &&
-                         !(d->wfrag_order == 1 && (x0.h % 2 != 0 || x0.w % 2 != 0 || d->stride != 2));   // odd sizes: generic gather
+                         !env_switches().no_halo && (d->q_oy | d->q_ox) == 0;
     // few-channel k x k layers (the 7x7 stems): tap-unit kernel (conv_kernel_tapunit.h)
     if (d->wfrag_order == 2) {
         const int unit = d->c0k % 8 == 0 ? 8 : 4;
@@ -294,7 +297,6 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         memset(&h, 0, sizeof(h));
         h.c = k;
         h.kh = d->kh; h.kw = d->kw; h.dil = d->dil; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
-        h.stride = d->stride;
         h.c1k = d->k_pad / (d->kh * d->kw) - d->c0k;
         h.wfrag = (const _Float16*)d->wfrag;
         h.nt32 = d->cout_pad / 32;
@@ -307,8 +309,8 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
         if (const int v = env_switches().halo_bn; (v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v;
         h.c.NT = d->cout_pad / bn;
         h.c.ksplit = 1;
-        h.HH = 7 * d->stride + (d->kh - 1) * d->dil + 1; h.HW = 15 * d->stride + (d->kw - 1) * d->dil + 1;
-        if (d->stride == 2 && d->wfrag_order == 1) {
+        h.HH = 7 + (d->kh - 1) * d->dil + 1; h.HW = 15 + (d->kw - 1) * d->dil + 1;
+        if (s2d_form) {
             // parity-quadrant form (include/fusg.h, wfrag_order): input row 2Y - 1 + ky = parity (ky-1)&1, sub-row Y + (ky-1 >> 1)
             if (!(d->kh == d->kw && (d->kh == 3 || d->kh == 4) && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 && !has1 &&
                   d->pad_mode != FUSG_PAD_REPLICATE)) {
@@ -316,8 +318,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                 prof_end(0, s);
                 return FUSG_ERR_INVALID;
             }
-            h.s2d = 1; h.stride = 1; h.HH = 10; h.HW = 18;
-            const int rp = halo_row_pitch(h.HW, false);
+            h.s2d = 1; h.HH = 10; h.HW = 18;
             int slab = 0;
             for (int q = 0; q < 4; ++q) {
                 h.qwoff[q] = slab;
@@ -327,7 +328,9 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
                     for (int kx = 0; kx < d->kw; ++kx) {
                         if (((kx - 1) & 1) != (q & 1)) continue;
                         const int dy = (ky - 1) >> 1, dx = (kx - 1) >> 1;          // arithmetic shift: floor
-                        h.qtoff[q][n++] = (dy + 1) * rp + (dx + 1) * 40;
+                        h.qtdy[q][n] = dy + 1;
+                        h.qtdx[q][n] = dx + 1;
+                        ++n;
                     }
                 }
                 h.qtaps[q] = n;
@@ -341,8 +344,7 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
             h.tile_list = d->tile_list; h.tile_count = d->tile_count;
             h.c.MT = (int)x0.n * d->tile_count;
         }
-        const int HP = h.HH * h.HW;
-        if ((HP * (halo_ch16(HP) ? 4 : 8) + 255) / 256 <= 10 && halo_lds_bytes(h.HH, h.HW) <= 96 * 1024) {
+        if (halo_fits(h.HH, h.HW)) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }

@@ -121,17 +121,10 @@ __device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, cons
 // comes back pixel-major, so each lane handles 4 consecutive channels of one pixel with 16-byte
 // accesses: 4x fewer memory instructions, 256-byte contiguous runs per pixel.
 // `pix(row, po)` maps a row of the wave tile to its destination pixel offsets (false = out of range).
+// second half of the vectorised epilogue: the wave's tile is in `wlds` ([TM*32 rows][TN*32 columns] floats)
 template <int TM, int TN, typename PixFn, typename StatFn>
-__device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const f32x16 (&acc)[TM][TN], int lane,
-                                             int ncol_base, PixFn pix, StatFn stat_base) {
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, float* wlds, int lane, int ncol_base, PixFn pix, StatFn stat_base) {
     constexpr int PITCH = TN * 32;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                wlds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -195,6 +188,36 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
             }
         }
     }
+}
+
+template <int TM, int TN, typename PixFn, typename StatFn>
+__device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const f32x16 (&acc)[TM][TN], int lane,
+                                             int ncol_base, PixFn pix, StatFn stat_base) {
+    constexpr int PITCH = TN * 32;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                wlds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
+    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base);
+}
+
+// the same for accumulators of v_mfma_f32_16x16x32_f16 tiles: acc[row group of 16][column group of 16], C/D map
+// col = lane & 15, row = (lane >> 4) * 4 + reg
+template <int TM, int TN, typename PixFn, typename StatFn>
+__device__ __forceinline__ void epilogue_vec16(const ConvK& p, float* wlds, const f32x4 (&acc)[2 * TM][2 * TN], int lane,
+                                               int ncol_base, PixFn pix, StatFn stat_base) {
+    constexpr int PITCH = TN * 32;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wlds[(i * 16 + (lane >> 4) * 4 + r) * PITCH + j * 16 + (lane & 15)] = acc[i][j][r];
+    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base);
 }
 
 // TM x TN 32x32 tiles per wave, WM x WN waves; PK = pre-op kind; GEN = generic addressing

@@ -1,19 +1,29 @@
-// Halo-tiled split-fp16 convolution for stride-1 k x k layers whose sources have a multiple of 32
-// channels (the layers that carry most of the FLOPs: 3x3 / dilated 3x3 / 5x5(+2x upsample) / 7x1).
+// Halo-tiled split-fp16 convolution for k x k layers whose sources have a multiple of 32 channels (the layers that
+// carry most of the FLOPs: 3x3 / dilated 3x3 / 5x5(+2x upsample) / 7x1 / 1x1, stride 1; stride-2 k3/k4 in
+// parity-quadrant form).
 //
-// The generic kernel (conv_kernel_h3.h) re-gathers and re-converts the A operand for every tap: for a
-// 3x3 layer every activation is fetched from L2, pre-processed (ELU / affine+ReLU) and split into
-// fp16 (hi, lo) nine times, and on gfx950 that VALU + L2 work - not the matrix pipe - is what bounds
-// it (measured: MFMA pipe 26 % busy).  Here a workgroup owns an 8 x 16 patch of output pixels of ONE
-// image and BN output channels.  For each 32-channel chunk of the input it stages the patch's halo
-// ((8+(kh-1)d) x (16+(kw-1)d) pixels) ONCE: gather -> pre-op -> fp16 split -> LDS.  All kh*kw taps
-// then read their A fragments from that LDS image at a constant per-tap offset; only the (static,
-// pre-split) weight tile of each (chunk, tap) streams through the double-buffered B stage.  Per
-// output tile this cuts the A-side L2 traffic and the staging VALU work by ~kh*kw.
+// The generic kernel (conv_kernel_h3.h) re-gathers and re-converts the A operand for every tap: for a 3x3 layer every
+// activation is fetched from L2, pre-processed (ELU / affine+ReLU) and split into fp16 (hi, lo') nine times, and on
+// gfx950 that VALU + L2 work - not the matrix pipe - is what bounds it (measured: MFMA pipe 26 % busy).  Here a
+// workgroup owns an 8 x 16 patch of output pixels of ONE image and BN output channels.  For each 32-channel chunk of
+// the input it stages the patch's halo ((8+(kh-1)d) x (16+(kw-1)d) pixels) ONCE: gather -> pre-op -> fp16 split ->
+// LDS.  All kh*kw taps then read their A fragments from that LDS image; only the (static, pre-split) weight tile of
+// each (chunk, tap) streams in.  Per output tile this cuts the A-side L2 traffic and the staging VALU work by ~kh*kw.
 //
-// Weights never touch LDS: pack.py stores them a second time in MFMA-fragment order, so the B operand of
-// every (tap, chunk, 32-column tile, 16-k half) is ONE contiguous 1 KiB wave load (16 B per lane) that
-// goes straight into registers, one step ahead of its use.  Waves therefore only meet at chunk
+// Contraction: v_mfma_f32_16x16x32_f16 (16 x 16 tiles, one instruction per 32 k = one staged chunk).  Same FLOPs per
+// cycle as 32x32x16, but under the board's power limit the chip holds a higher clock on this shape
+// (MI355X_MICROARCH.md, DVFS give-back item 7): measured on the layers of the crop pass, sustained, same card, same
+// run: 256->256 3x3 372 -> 412 TFLOP/s, 128->128 3x3 @256 322 -> 348, 5x5+upsample 256->128 402 -> 464, dilated 3x3
+// 363 -> 395, joules per launch -8..-13 % (profiles/r02_halo_m16_ab.txt).
+// A fragments: one patch row (16 pixels) x 32 channels per instruction: lane l = pixel l & 15, channels
+// 8 (l >> 4) .. +8.  The halo image has a 64-byte pixel pitch (no padding) and the 16-byte channel slot g of halo
+// column hx is stored at slot g ^ 2 ((hx >> 2) & 1): with that swizzle the four 16-lane service groups of a
+// ds_read_b128 each touch 16 distinct 16-byte bank groups for EVERY tap shift (exhaustive search over pitches 64-144 B
+// and 4-class swizzles; the unswizzled 64- and 80-byte pitches are 2-way conflicted on this operand shape).
+//
+// Weights never touch LDS: pack.py stores them a second time in MFMA-fragment order (lane l: column l & 15, k
+// 8 (l >> 4) .. +8), so the B operand of every (tap, chunk, 16-column tile) is ONE contiguous 1 KiB wave load (16 B
+// per lane) that goes straight into registers, one step ahead of its use.  Waves therefore only meet at chunk
 // boundaries (two barriers per kh*kw taps) instead of once per tap.
 //
 // Loop nest: source -> 32-channel chunk -> tap;  K index of a (chunk, tap) weight tile in the packed
@@ -26,8 +36,8 @@
 
 namespace fusg {
 
-// halo LDS pitch in halves = CH + 8 (80 B for 32-channel chunks, 48 B for 16): unswizzled, <= 2-way conflicts,
-// 16-byte aligned rows
+constexpr int HALO_CH = 32;          // channels per staged chunk = k per MFMA
+constexpr int HALO_PP = 32;          // halo pixel pitch in halves (64 B, slots swizzled - see above)
 
 struct HaloK {
     ConvK c;
@@ -36,16 +46,15 @@ struct HaloK {
     int RP;                     // LDS pitch of a halo row in halves (halo_row_pitch)
     int tiles_x, tiles_per_img;
     int c1k;                    // K-channels of src1 (0 if absent)
-    int stride;                 // 1 or 2 (stride-2 layers stage 16-channel chunks: their halo is ~4x larger)
     const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
     const int* tile_list;       // optional: patch indices (within an image) to compute; MT = B * tile_count
     int tile_count;
     // Stride-2 k3/k4 pad-1 layers as four stride-1 convolutions of the parity sub-images x[2Y+i, 2X+j] (q = 2i+j):
     // a chunk is then (quadrant, 32 channels) with its own short tap list; LDS reads stay unit-stride.
-    int s2d;                    // 1: quadrant form (stride above is 1, HH x HW = 10 x 18 sub-image pixels)
+    int s2d;                    // 1: quadrant form of a stride-2 layer (HH x HW = 10 x 18 sub-image pixels)
     int qtaps[4];               // taps of each quadrant
     int qwoff[4];               // first weight slab of each quadrant (slabs of a quadrant are consecutive)
-    int qtoff[4][4];            // LDS offset (halves) of each (quadrant, local tap)
+    int qtdy[4][4], qtdx[4][4]; // halo pixel offset (rows, columns) of each (quadrant, local tap)
     int nt32;                   // cout_pad / 32
 };
 
@@ -59,13 +68,11 @@ __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, in
     o.r1 = b * p.r1n + Y * p.r1h + X * p.r1w;
 }
 
-template <int TM, int TN, int WM, int WN, int PK, int NI, int CH>
+template <int TM, int TN, int WM, int WN, int PK, int NI>
 __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK hk) {
-    constexpr int HPITCH = CH + 8;                 // halves
+    constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
-    constexpr int LOGC = CH == 32 ? 3 : 2;
-    constexpr int NC16 = CH / 16;                  // 16-k MFMA chunks per staged chunk
-    static_assert(CH == 32 || CH == 16, "chunk size");
+    constexpr int LOGC = 3;
     const ConvK& p = hk.c;
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
@@ -109,8 +116,8 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
         if (pix < HP) {
             hexist |= 1u << j;
             const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
-            hoff[j] = hy * hk.RP + hx * HPITCH + kc * 4;
-            int vy = oy0 * hk.stride - hk.pad_h + hy, vx = ox0 * hk.stride - hk.pad_w + hx;
+            hoff[j] = hy * hk.RP + hx * HPITCH + ((((kc >> 1) ^ (((hx >> 2) & 1) << 1)) << 3) | ((kc & 1) << 2));
+            int vy = oy0 - hk.pad_h + hy, vx = ox0 - hk.pad_w + hx;
             bool ok = true;
             if (hk.s2d) {
                 // sub-image coordinates; reflection of the full image at -1 / H is a clamp of the sub-image
@@ -188,62 +195,60 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
             }
         }
     };
-    struct BFrag { h8 f[TN][NC16][2]; };              // [column tile][16-k chunk][hi, lo]
+    struct BFrag { h8 f[TN][2][2]; };                 // [32-column tile][16-column half][hi, lo]
     BFrag bfA, bfB;
     auto b_load = [&](BFrag& F, int cg, int tap) {
-        int k16 = cg * NC16;                                        // first 16-k chunk of this staged chunk
-        if (hk.s2d) { const int q = cg / nchq; tap += hk.qwoff[q]; k16 = (cg - q * nchq) * NC16; }
-        const _Float16* base = wfr + (long)(tap * nch32 + (k16 >> 1)) * wstep;
+        int ch32 = cg;                                              // 32-channel chunk within its tap's K range
+        if (hk.s2d) { const int q = cg / nchq; tap += hk.qwoff[q]; ch32 = cg - q * nchq; }
+        const _Float16* base = wfr + (long)(tap * nch32 + ch32) * wstep;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int c = 0; c < NC16; ++c)
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl)
-                    F.f[j][c][hl] = *(const h8*)(base + ((j * 2 + (k16 & 1) + c) * 2 + hl) * 512);
+                    F.f[j][ct][hl] = *(const h8*)(base + ((j * 2 + ct) * 2 + hl) * 512);
     };
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[2 * TM][2 * TN];                        // [patch row of the wave][16-column group]
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // row group i of the wave (16 output pixels) = patch row wm*TM*2 + i; lane l reads pixel l & 15 of it
+    int abase[2 * TM];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) abase[i] = (wm * TM * 2 + i) * hk.RP;
+    auto compute = [&](int cg, int tap, const BFrag& F) {
+        int dyp, dxp;                                                  // halo pixel offset of the tap
+        if (hk.s2d) { const int q = cg / nchq; dyp = hk.qtdy[q][tap]; dxp = hk.qtdx[q][tap]; }
+        else { const int ky = tap / hk.kw, kx = tap - ky * hk.kw; dyp = ky * hk.dil; dxp = kx * hk.dil; }
+        const int hx = (lane & 15) + dxp;
+        const int toff = dyp * hk.RP + hx * HPITCH + (((lane >> 4) ^ (((hx >> 2) & 1) << 1)) << 3);
+        h8 ah[2 * TM], al[2 * TM], bs[TN][2];
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {
+            ah[i] = *(const h8*)(Ah + abase[i] + toff);
+            al[i] = *(const h8*)(Al + abase[i] + toff);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // lane -> halo pixel of its A rows (tap (0,0)); row = wm*TM*32 + i*32 + (lane&31) -> (py, px) = (row>>4, row&15)
-    int abase[TM];
+            for (int ct = 0; ct < 2; ++ct) bs[j][ct] = scale_m11(F.f[j][ct][0]);   // wh * 2^-11: B operand of the al' term
+        // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one accumulator
+        // stalls the issue)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm * TM * 32 + i * 32 + (lane & 31);
-        abase[i] = (row >> 4) * hk.stride * hk.RP + (row & 15) * hk.stride * HPITCH + (lane >> 5) * 8;
-    }
-    auto compute = [&](int cg, int tap, const BFrag& F) {
-        const int ky = tap / hk.kw, kx = tap - ky * hk.kw;
-        const int toff = hk.s2d ? hk.qtoff[cg / nchq][tap] : ky * hk.dil * hk.RP + kx * hk.dil * HPITCH;
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int c = 0; c < NC16; ++c) {
-            h8 ah[TM], al[TM];
+            for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *(const h8*)(Ah + abase[i] + toff + c * 16);
-                al[i] = *(const h8*)(Al + abase[i] + toff + c * 16);
-            }
-            h8 bs[TN];                                             // wh * 2^-11: B operand of the al' term
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bs[j] = scale_m11(F.f[j][c][0]);
-            // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one
-            // accumulator stalls the issue: measured SQ_WAIT_INST_ANY 50 % with the accumulator-major order)
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i],
-                                                                           term == 0 ? F.f[j][c][0] : term == 1 ? F.f[j][c][1] : bs[j],
-                                                                           acc[i][j], 0, 0, 0);
-        }
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            term == 2 ? al[i] : ah[i], term == 0 ? F.f[j][ct][0] : term == 1 ? F.f[j][ct][1] : bs[j][ct],
+                            acc[i][2 * j + ct], 0, 0, 0);
     };
 
     // ---- prologue: halo of chunk 0 and the first weight fragments
@@ -276,74 +281,62 @@ __global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK
 
     report_range(p, amax);
     // ---------------------------------------------------------------- epilogue
-    const int ncol0 = nt * BN + wn * TN * 32 + (lane & 31);
+    auto pixfn = [&](int row, PixOff& po) {
+        const int rr = wm * TM * 32 + row;
+        pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
+        return true;
+    };
+    auto statfn = [&](int i) -> float* {                       // slot = (patch index, 32-row group of the patch)
+        return p.stats + ((long)b * p.stats_slots + t2 * 4 + ((wm * TM * 32) >> 5) + i) * p.Cout * 2;
+    };
     if (p.vec_epi) {
         __syncthreads();
         float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
-        const int rwave = wm * TM * 32;
-        epilogue_vec<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, [&](int row, PixOff& po) {
-            const int rr = rwave + row;
-            pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
-            return true;
-        }, [&](int i) -> float* {                          // slot = (patch index, 32-row group of the patch)
-            return p.stats + ((long)b * p.stats_slots + t2 * 4 + (rwave >> 5) + i) * p.Cout * 2;
-        });
+        epilogue_vec16<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn);
         return;
     }
-    PixOff co[TN];
-    float bias[TN], wsc[TN];
-    bool nok[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = ncol0 + j * 32;
-        nok[j] = n < p.Cout;
-        bias[j] = p.bias[n];
-        wsc[j] = p.wscale ? p.wscale[n] : 1.f;
-        chan_offsets(p, n, co[j]);
+    for (int j = 0; j < 2 * TN; ++j) {                     // C/D map of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+        const int n = nt * BN + wn * TN * 32 + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        PixOff co;
+        chan_offsets(p, n, co);
+        const float bias = p.bias[n], wsc = p.wscale ? p.wscale[n] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * TM * 32 + i * 16 + (lane >> 4) * 4 + r;
+                PixOff po;
+                pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
+                epi_store(p, po, co, bias, wsc, acc[i][j][r]);
+            }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            PixOff po;
-            pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (nok[j]) epi_store(p, po, co[j], bias[j], wsc[j], acc[i][j][r]);
-        }
 }
 
-// Staging shape of a halo of HP pixels: 32-channel chunks while every thread holds at most 10 16-byte items,
-// else (the ~4x larger stride-2 halos) 16-channel chunks.
-inline bool halo_ch16(int HP) { return HP * 8 > 2560; }
-// LDS pitch of one halo row in halves.  Stride-1 layers (32-channel chunks, 80-byte pixels): rounded up to a
-// multiple of 256 B.  A ds_read_b128 is served in groups of 16 lanes that hold pixels {0-3, 12-15} of one patch
-// row and {4-11} of the next (MI355X_MICROARCH.md, LDS); consecutive 80-byte pixels already spread over the 64
-// banks, so a group is conflict-free exactly when the two rows sit a multiple of 256 B apart (measured with the
-// natural pitch: 47 % of the LDS cycles were bank-conflict replays).
-inline int halo_row_pitch(int HW, bool ch16) { return ch16 ? HW * 24 : (HW * 40 + 127) / 128 * 128; }
-inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_pitch(HW, halo_ch16(HH * HW)) * sizeof(_Float16); }
+// LDS pitch of one halo row in halves (rows need no padding: one ds_read_b128 instruction reads one patch row)
+inline int halo_row_pitch(int HW) { return HW * HALO_PP; }
+inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_pitch(HW) * sizeof(_Float16); }
+// a thread stages at most 10 16-byte items of a 32-channel chunk: halos of up to 320 pixels
+inline bool halo_fits(int HH, int HW) { return HH * HW * 8 <= 2560 && halo_lds_bytes(HH, HW) <= 96 * 1024; }
 
 template <int TM, int TN, int WM, int WN>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     const int HP = k.HH * k.HW;
-    const bool ch16 = halo_ch16(HP);
     size_t lds = halo_lds_bytes(k.HH, k.HW);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
-    const int ni = (HP * (ch16 ? 4 : 8) + 255) / 256;
-    if (ni > 10 || lds > 96 * 1024) return hipErrorInvalidValue;
+    const int ni = (HP * 8 + 255) / 256;
+    if (!halo_fits(k.HH, k.HW)) return hipErrorInvalidValue;
     const void* fn = nullptr;
 #define FUSG_PICK_NI(PKV)                                                                         \
-    if (ch16) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 16>;                          \
-    else if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, 32>;                   \
-    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, 32>;                   \
-    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, 32>;
+    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6>;                          \
+    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8>;                     \
+    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10>;
     if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU) } else { FUSG_PICK_NI(PK_AFFINE) }
 #undef FUSG_PICK_NI
     if (hipError_t e = ensure_dyn_lds(fn, 96 * 1024); e != hipSuccess) return e;
     HaloK kk = k;
-    kk.RP = halo_row_pitch(k.HW, ch16);
+    kk.RP = halo_row_pitch(k.HW);
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }

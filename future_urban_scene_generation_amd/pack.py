@@ -119,17 +119,17 @@ def split_f16x3(wpack: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:
     """MFMA-fragment order of the split weights for the halo kernel (csrc/conv_kernel_halo.h):
-    [tap][chunk32][cout_pad/32][k half (16)][hi|lo][lane 64][8 halves], lane = (k>>3 & 1)*32 + column,
-    i.e. exactly what lane l of a wave feeds v_mfma_f32_32x32x16_f16 as B[k = 8*(l>>5) + j][col = l&31].
-    Returns None when the layer cannot use that kernel (channels not a multiple of 32 per source)."""
+    [tap][chunk32][cout_pad/32][16-column half][hi|lo][lane 64][8 halves], lane = (k >> 3) * 16 + column, i.e. exactly
+    what lane l of a wave feeds v_mfma_f32_16x16x32_f16 as B[k = 8*(l>>4) + j][col = l&15]: one fragment per
+    (32 k, 16 columns).  Returns None when the layer cannot use that kernel (channels not a multiple of 32 per source)."""
     taps = plan.kh * plan.kw
     ctot = plan.c0k + plan.c1k
     if plan.nphase != 1 or taps < 1 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
         return None
     w = wsplit[0]                                               # [2 (hi, lo), cout_pad, k_pad]
     nt32, nch = plan.cout_pad // 32, ctot // 32
-    w = w.view(2, nt32, 32, taps, nch, 2, 2, 8)                 # hl, nt, r, tap, chunk, c16, h, j
-    w = w.permute(3, 4, 1, 5, 0, 6, 2, 7)                       # tap, chunk, nt, c16, hl, h, r, j
+    w = w.view(2, nt32, 2, 16, taps, nch, 4, 8)                 # hl, nt, ct, r, tap, chunk, g, j
+    w = w.permute(4, 5, 1, 2, 0, 6, 3, 7)                       # tap, chunk, nt, ct, hl, g, r, j
     return w.reshape(taps, nch, nt32, 2, 2, 64, 8).contiguous()
 
 

@@ -140,22 +140,23 @@ typedef struct fusg_conv_desc {
     int32_t ksplit;              /* <=1: no split-K                                            */
     int32_t precision;           /* fusg_precision                                             */
     const void*    wpack_h;      /* F16X3 only: [nphase][2][cout_pad][k_pad] fp16 = (hi, lo) of w * s[n]   */
-    /* Optional filter geometry (0 = unknown).  When given and the layer qualifies (F16X3, stride 1,
-     * nphase 1, source channels % 32 == 0, qh % 8 == 0, qw % 16 == 0) the halo-tiled kernel
+    /* Optional filter geometry (0 = unknown).  When given and the layer qualifies (F16X3, stride 1 - or stride 2
+     * with wfrag_order 1 -, nphase 1, source channels % 32 == 0, qh % 8 == 0, qw % 16 == 0) the halo-tiled kernel
      * is used: taps must then be the dense kh x kw grid in (ky, kx) order with
      * dy = ky*dil - pad_h, dx = kx*dil - pad_w, which is what pack.py emits. */
     int32_t kh, kw, dil, pad_h, pad_w;
     int32_t wfrag_order;         /* 0: wfrag slabs in tap order.  1 (stride 2, k3/k4, pad 1, dil 1, one source with
                                     channels % 32 == 0, even H and W): slabs grouped by the parity quadrant of the input
                                     they read (pack.py: s2d_tap_order) - the launch then runs as four stride-1
-                                    convolutions of the quarter-size parity sub-images (halo kernel, 32-channel
-                                    chunks, unit-stride LDS reads) instead of the strided form.
+                                    convolutions of the quarter-size parity sub-images on the halo kernel (odd
+                                    H or W: generic gather).
                                     2 (one source with 4..24 channels, dil 1, k x k taps): wfrag holds the weights per
                                     16-k step of the tap-unit kernel (pack.py: frag_tapunit) - the whole few-channel
                                     halo is staged once and K runs over (tap, 8- or 4-channel unit)              */
     /* Halo kernel only: the (hi, lo) fp16 weights again, in MFMA-fragment order
-     * [tap][chunk32][cout_pad/32][k-half][hi|lo][64 lanes][8 halves] (pack.py: frag_f16x3), so that a
-     * B operand is one contiguous 1 KiB wave load.  NULL disables the halo kernel. */
+     * [tap][chunk32][cout_pad/32][16-column half][hi|lo][64 lanes][8 halves], lane = (k >> 3) * 16 + column
+     * (pack.py: frag_f16x3) = the B operand of v_mfma_f32_16x16x32_f16, so that a fragment is one contiguous
+     * 1 KiB wave load.  NULL disables the halo kernel. */
     const void*    wfrag;
     /* Optional fused normalisation statistics of the conv OUTPUT (bias included): per image and per
      * 32-pixel slot (slot order is kernel-defined; finalisation is order-independent) the mean and the
