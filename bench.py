@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
     ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
     ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
+    ap.add_argument("--replay", action="store_true",
+                    help="issue each pass as ONE recorded-plan replay (fusg_plan) instead of ~370 launches from Python: "
+                         "matters at small --batch, where the interpreter bounds the pass")
     ap.add_argument("--precision", choices=["f16x3", "f32", "both"], default="both",
                     help="which precision legs to time (default both; the headline is f16x3 when it ran)")
     return ap.parse_args()
@@ -273,11 +276,18 @@ def main():
     # on how the vehicles are spread over ranks
     seeds = [1000 + first + i for i in range(args.batch)]
     gather_ms = []
+    compiled = {}
 
     def step():
         # check="async": the range guard's status word is read once, after the timed steps (pipe.finish()), instead of
         # synchronising the host after every pass
-        out = pipe.run(batch, vehicle_seeds=seeds, check="async")
+        if args.replay and os.environ.get("FUSG_STREAMS", "1") != "0":
+            cp = compiled.get(ops.PRECISION)
+            if cp is None:
+                cp = compiled[ops.PRECISION] = pipe.compile(batch, seeds)
+            out = cp.run(batch, vehicle_seeds=seeds, check="async")
+        else:
+            out = pipe.run(batch, vehicle_seeds=seeds, check="async")
         if world > 1:                                   # the path's only exchange: crops -> rank 0
             t_g = time.perf_counter()
             crops = torch.cat([out["icn_u8"], out["vunet_u8"]], dim=-1)
@@ -465,6 +475,7 @@ def main():
             line["power"] = h["power"]
         line["settle_steps"] = h["settle_steps"]
         line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch"
+        line["issue"] = "recorded plan replay (fusg_plan_run)" if args.replay else "eager (one ctypes call per launch)"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -84,6 +84,15 @@ _SIGS = {
     "fusg_icn_inputs": (C.c_int, [_TP, _TP, _TP, C.c_void_p, _TP, C.c_void_p]),
     "fusg_lab2bgr_u8": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_paste_back_u8": (C.c_int, [_TP, _TP, C.c_void_p, _TP, C.c_void_p]),
+    "fusg_plan_create": (C.c_void_p, []),
+    "fusg_plan_destroy": (None, [C.c_void_p]),
+    "fusg_plan_begin": (C.c_int, [C.c_void_p]),
+    "fusg_plan_end": (C.c_int, [C.c_void_p]),
+    "fusg_plan_add_dependency": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fusg_plan_add_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
+    "fusg_plan_next_slot": (C.c_int, [C.c_void_p]),
+    "fusg_plan_size": (C.c_int64, [C.c_void_p]),
+    "fusg_plan_run": (C.c_int, [C.c_void_p]),
     "fusg_version": (C.c_int, []),
     "fusg_last_error": (C.c_char_p, []),
     "fusg_last_conv_kernel": (C.c_int, []),

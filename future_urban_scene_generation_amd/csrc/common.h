@@ -1,6 +1,10 @@
 // Shared host-side helpers for libfusg (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
+#include <memory>
+#include <tuple>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -54,6 +58,40 @@ hipError_t ensure_dyn_lds(const void* fn, int bytes);
 // FUSG_HALO_MINWG, FUSG_HALO_BN (tools/README.md).  (api.hip)
 struct EnvSwitches { bool no_vec_epi, no_halo; long halo_minwg; int halo_bn; };
 const EnvSwitches& env_switches();
+
+// ---- recorded passes (plan.hip) ----------------------------------------------------------------------------------
+// While a fusg_plan is recording on this thread, every launching entry point appends a closure of itself - its
+// descriptors copied by value, its stream - to the plan before executing; fusg_plan_run replays the closures in order.
+void plan_append(hipStream_t stream, std::function<int(hipStream_t)> fn);
+bool plan_recording();
+
+template <class A> struct SavedArg {                       // scalars and raw device pointers: by value
+    A a;
+    explicit SavedArg(A v) : a(v) {}
+    A get() const { return a; }
+};
+template <> struct SavedArg<const fusg_tensor*> {          // descriptors: copied (NULL stays NULL)
+    bool has; fusg_tensor t;
+    explicit SavedArg(const fusg_tensor* p) : has(p != nullptr), t(p ? *p : fusg_tensor{}) {}
+    const fusg_tensor* get() const { return has ? &t : nullptr; }
+};
+template <> struct SavedArg<const fusg_conv_desc*> {
+    bool has; fusg_conv_desc d;
+    explicit SavedArg(const fusg_conv_desc* p) : has(p != nullptr), d(p ? *p : fusg_conv_desc{}) {}
+    const fusg_conv_desc* get() const { return has ? &d : nullptr; }
+};
+
+// run impl(args..., stream); when a plan is recording, remember the call first
+template <class... A>
+int plan_dispatch(int (*impl)(A..., void*), void* stream, A... a) {
+    if (plan_recording()) {
+        auto saved = std::make_shared<std::tuple<SavedArg<A>...>>(SavedArg<A>(a)...);
+        plan_append((hipStream_t)stream, [impl, saved](hipStream_t s) {
+            return std::apply([&](const SavedArg<A>&... sv) { return impl(sv.get()..., (void*)s); }, *saved);
+        });
+    }
+    return impl(a..., stream);
+}
 
 // profiler (api.hip)
 void prof_begin(int kind, hipStream_t s, double flops);

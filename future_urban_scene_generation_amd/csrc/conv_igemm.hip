@@ -94,7 +94,7 @@ using namespace fusg;
 
 extern "C" int64_t fusg_conv2d_plan(fusg_conv_desc* d) { return plan_impl(d); }
 
-extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
+static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     fusg_conv_desc dd = *din;
     fusg_conv_desc* d = &dd;
     hipStream_t s = (hipStream_t)stream;
@@ -385,3 +385,4 @@ extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) {
     prof_end(0, s);
     return FUSG_OK;
 }
+extern "C" int fusg_conv2d(const fusg_conv_desc* din, void* stream) { return fusg::plan_dispatch(conv2d_impl, stream, din); }

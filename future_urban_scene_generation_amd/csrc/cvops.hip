@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void paste_back_kernel(PasteIn a, long total) 
 
 using namespace fusg;
 
-extern "C" int fusg_warp_perspective_u8(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream) {
+static int warp_perspective_u8_impl(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(src && dst && minv && is_u8_hwc(*src, 3) && is_u8_hwc(*dst, 3) && src->n == dst->n, "warp_perspective_u8: u8 HWC tensors of 3 channels, same n");
     FUSG_CHECK(src->data != dst->data, "warp_perspective_u8: in-place not supported");
     const long total = dst->n * dst->h * dst->w;
@@ -336,6 +336,7 @@ extern "C" int fusg_warp_perspective_u8(const fusg_tensor* src, const double* mi
     FUSG_LAUNCH_CHECK("warp_perspective_u8");
     return FUSG_OK;
 }
+extern "C" int fusg_warp_perspective_u8(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(warp_perspective_u8_impl, stream, src, minv, dst); }
 
 extern "C" int fusg_fill_poly_planes_u8(const fusg_tensor* frame, const int32_t* pts_xy, const int32_t* nverts, int32_t nplanes,
                                         const fusg_tensor* dst, void* stream) {
@@ -354,7 +355,7 @@ extern "C" int fusg_fill_poly_planes_u8(const fusg_tensor* frame, const int32_t*
     return FUSG_OK;
 }
 
-extern "C" int fusg_icn_inputs(const fusg_tensor* sketch, const fusg_tensor* central, const fusg_tensor* planes, const int32_t* geom,
+static int icn_inputs_impl(const fusg_tensor* sketch, const fusg_tensor* central, const fusg_tensor* planes, const int32_t* geom,
                                const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(sketch && central && planes && geom && dst && is_u8_hwc(*sketch, 3) && is_u8_hwc(*central, 3) && is_u8_hwc(*planes, 3),
                "icn_inputs: u8 HWC inputs");
@@ -373,16 +374,18 @@ extern "C" int fusg_icn_inputs(const fusg_tensor* sketch, const fusg_tensor* cen
     FUSG_LAUNCH_CHECK("icn_inputs");
     return FUSG_OK;
 }
+extern "C" int fusg_icn_inputs(const fusg_tensor* sketch, const fusg_tensor* central, const fusg_tensor* planes, const int32_t* geom, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(icn_inputs_impl, stream, sketch, central, planes, geom, dst); }
 
-extern "C" int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream) {
+static int lab2bgr_u8_impl(const fusg_tensor* src, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(src && dst && is_u8_hwc(*src, 3) && is_u8_hwc(*dst, 3) && src->n == dst->n && src->h == dst->h && src->w == dst->w, "lab2bgr_u8: shapes");
     const long total = dst->n * dst->h * dst->w;
     hipLaunchKernelGGL(lab2bgr_u8_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, u8view(*src), u8view(*dst), total);
     FUSG_LAUNCH_CHECK("lab2bgr_u8");
     return FUSG_OK;
 }
+extern "C" int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(lab2bgr_u8_impl, stream, src, dst); }
 
-extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) {
+static int paste_back_u8_impl(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) {
     FUSG_CHECK(net && masks && geom && frame && is_u8_hwc(*net, 3) && is_u8_hwc(*frame, 3) && frame->n == 1 && masks->data &&
                masks->dtype == FUSG_U8 && masks->c == 1 && masks->n == net->n && masks->h == frame->h && masks->w == frame->w, "paste_back_u8: shapes");
     PasteIn a;
@@ -392,3 +395,4 @@ extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* mas
     FUSG_LAUNCH_CHECK("paste_back_u8");
     return FUSG_OK;
 }
+extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) { return fusg::plan_dispatch(paste_back_u8_impl, stream, net, masks, geom, frame); }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void merge_u8_kernel(T4 o, T4 img, T4 msk, T4 
 
 using namespace fusg;
 
-extern "C" int fusg_affine_act(const fusg_tensor* x, const float* scale, const float* shift, int64_t bstride, int32_t act,
+static int affine_act_impl(const fusg_tensor* x, const float* scale, const float* shift, int64_t bstride, int32_t act,
                                const fusg_tensor* res, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(x && dst && is_nhwc(*x) && is_nhwc(*dst) && same_shape(*x, *dst) && x->c % 4 == 0,
                "affine_act: x/dst must be NHWC-physical, same shape, C%%4==0");
@@ -324,8 +324,9 @@ extern "C" int fusg_affine_act(const fusg_tensor* x, const float* scale, const f
     FUSG_LAUNCH_CHECK("affine_act");
     return FUSG_OK;
 }
+extern "C" int fusg_affine_act(const fusg_tensor* x, const float* scale, const float* shift, int64_t bstride, int32_t act, const fusg_tensor* res, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(affine_act_impl, stream, x, scale, shift, bstride, act, res, dst); }
 
-extern "C" int fusg_maxpool2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
+static int maxpool2_impl(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(x && dst && is_nhwc(*x) && is_nhwc(*dst) && x->c % 4 == 0 && x->c == dst->c && x->n == dst->n &&
                x->h == 2 * dst->h && x->w == 2 * dst->w, "maxpool2: shapes (needs even H,W, NHWC-physical)");
     const int C4 = (int)(x->c / 4);
@@ -337,8 +338,9 @@ extern "C" int fusg_maxpool2(const fusg_tensor* x, const fusg_tensor* dst, void*
     FUSG_LAUNCH_CHECK("maxpool2");
     return FUSG_OK;
 }
+extern "C" int fusg_maxpool2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(maxpool2_impl, stream, x, dst); }
 
-extern "C" int fusg_upsample2_add(const fusg_tensor* low, const fusg_tensor* up1, const fusg_tensor* dst, void* stream) {
+static int upsample2_add_impl(const fusg_tensor* low, const fusg_tensor* up1, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(low && up1 && dst && is_nhwc(*low) && is_nhwc(*up1) && is_nhwc(*dst) && same_shape(*up1, *dst) &&
                up1->c % 4 == 0 && low->c == up1->c && low->n == up1->n && up1->h == 2 * low->h && up1->w == 2 * low->w,
                "upsample2_add: shapes");
@@ -351,8 +353,9 @@ extern "C" int fusg_upsample2_add(const fusg_tensor* low, const fusg_tensor* up1
     FUSG_LAUNCH_CHECK("upsample2_add");
     return FUSG_OK;
 }
+extern "C" int fusg_upsample2_add(const fusg_tensor* low, const fusg_tensor* up1, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(upsample2_add_impl, stream, low, up1, dst); }
 
-extern "C" int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32_t dst_c_fill, void* stream) {
+static int copy4d_impl(const fusg_tensor* src, const fusg_tensor* dst, int32_t dst_c_fill, void* stream) {
     FUSG_CHECK(src && dst && src->data && dst->data && src->dtype == FUSG_F32 && dst->dtype == FUSG_F32, "copy4d: f32 tensors required");
     FUSG_CHECK(same_nhw(*src, *dst) && src->c <= dst->c && dst_c_fill <= dst->c, "copy4d: shape mismatch");
     const long HW = src->h * src->w;
@@ -370,8 +373,9 @@ extern "C" int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32
     FUSG_LAUNCH_CHECK("copy4d");
     return FUSG_OK;
 }
+extern "C" int fusg_copy4d(const fusg_tensor* src, const fusg_tensor* dst, int32_t dst_c_fill, void* stream) { return fusg::plan_dispatch(copy4d_impl, stream, src, dst, dst_c_fill); }
 
-extern "C" int fusg_add4d(const fusg_tensor* a, const fusg_tensor* b, const fusg_tensor* dst, void* stream) {
+static int add4d_impl(const fusg_tensor* a, const fusg_tensor* b, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(a && b && dst && a->data && b->data && dst->data && same_shape(*a, *b) && same_shape(*a, *dst) &&
                a->dtype == FUSG_F32 && b->dtype == FUSG_F32 && dst->dtype == FUSG_F32, "add4d: shape/dtype mismatch");
     const long total = dst->n * dst->h * dst->w * dst->c;
@@ -379,8 +383,9 @@ extern "C" int fusg_add4d(const fusg_tensor* a, const fusg_tensor* b, const fusg
     FUSG_LAUNCH_CHECK("add4d");
     return FUSG_OK;
 }
+extern "C" int fusg_add4d(const fusg_tensor* a, const fusg_tensor* b, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(add4d_impl, stream, a, b, dst); }
 
-extern "C" int fusg_space_to_depth2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
+static int space_to_depth2_impl(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(x && dst && is_nhwc(*x) && is_nhwc(*dst) && x->c % 4 == 0 && dst->c == 4 * x->c && x->h == 2 * dst->h &&
                x->w == 2 * dst->w && x->n == dst->n, "space_to_depth2: shapes");
     const int C4 = (int)(x->c / 4);
@@ -390,8 +395,9 @@ extern "C" int fusg_space_to_depth2(const fusg_tensor* x, const fusg_tensor* dst
     FUSG_LAUNCH_CHECK("space_to_depth2");
     return FUSG_OK;
 }
+extern "C" int fusg_space_to_depth2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(space_to_depth2_impl, stream, x, dst); }
 
-extern "C" int fusg_depth_to_space2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
+static int depth_to_space2_impl(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(x && dst && is_nhwc(*x) && is_nhwc(*dst) && x->c % 16 == 0 && x->c == 4 * dst->c && dst->h == 2 * x->h &&
                dst->w == 2 * x->w && x->n == dst->n, "depth_to_space2: shapes");
     const int C4 = (int)(dst->c / 4);
@@ -401,8 +407,9 @@ extern "C" int fusg_depth_to_space2(const fusg_tensor* x, const fusg_tensor* dst
     FUSG_LAUNCH_CHECK("depth_to_space2");
     return FUSG_OK;
 }
+extern "C" int fusg_depth_to_space2(const fusg_tensor* x, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(depth_to_space2_impl, stream, x, dst); }
 
-extern "C" int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edges, const fusg_tensor* masks,
+static int ec_inputs_impl(const fusg_tensor* images, const fusg_tensor* edges, const fusg_tensor* masks,
                               const fusg_tensor* dst, int32_t mode, void* stream) {
     FUSG_CHECK(images && edges && masks && dst && images->data && edges->data && masks->data && dst->data, "ec_inputs: null tensor");
     FUSG_CHECK(mode == 0 || mode == 1, "ec_inputs: mode");
@@ -414,8 +421,9 @@ extern "C" int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edge
     FUSG_LAUNCH_CHECK("ec_inputs");
     return FUSG_OK;
 }
+extern "C" int fusg_ec_inputs(const fusg_tensor* images, const fusg_tensor* edges, const fusg_tensor* masks, const fusg_tensor* dst, int32_t mode, void* stream) { return fusg::plan_dispatch(ec_inputs_impl, stream, images, edges, masks, dst, mode); }
 
-extern "C" int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t kw, int32_t pad, int32_t pad_mode, int32_t act,
+static int hshift_sum_impl(const fusg_tensor* t, const float* bias, int32_t kw, int32_t pad, int32_t pad_mode, int32_t act,
                                const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(t && dst && bias && is_nhwc(*t) && dst->data && dst->dtype == FUSG_F32 && same_nhw(*t, *dst), "hshift_sum: tensors");
     FUSG_CHECK(kw >= 1 && kw <= 15 && pad >= 0 && pad < dst->w && dst->c * kw <= t->c, "hshift_sum: kw %d pad %d cout %ld tc %ld", kw, pad, (long)dst->c, (long)t->c);
@@ -435,15 +443,17 @@ extern "C" int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t 
     FUSG_LAUNCH_CHECK("hshift_sum");
     return FUSG_OK;
 }
+extern "C" int fusg_hshift_sum(const fusg_tensor* t, const float* bias, int32_t kw, int32_t pad, int32_t pad_mode, int32_t act, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(hshift_sum_impl, stream, t, bias, kw, pad, pad_mode, act, dst); }
 
-extern "C" int fusg_argmax_hw(const fusg_tensor* x, int32_t* idx, void* stream) {
+static int argmax_hw_impl(const fusg_tensor* x, int32_t* idx, void* stream) {
     FUSG_CHECK(x && x->data && idx && x->dtype == FUSG_F32 && x->h * x->w >= 1 && x->h * x->w < (1L << 30), "argmax_hw: bad tensor");
     hipLaunchKernelGGL(argmax_hw_kernel, dim3((unsigned)(x->n * x->c)), dim3(256), 0, (hipStream_t)stream, view(*x), idx);
     FUSG_LAUNCH_CHECK("argmax_hw");
     return FUSG_OK;
 }
+extern "C" int fusg_argmax_hw(const fusg_tensor* x, int32_t* idx, void* stream) { return fusg::plan_dispatch(argmax_hw_impl, stream, x, idx); }
 
-extern "C" int fusg_to_image_u8(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
+static int to_image_u8_impl(const fusg_tensor* x, const fusg_tensor* dst, void* stream) {
     FUSG_CHECK(x && dst && x->data && dst->data && x->dtype == FUSG_F32 && dst->dtype == FUSG_U8 && same_shape(*x, *dst),
                "to_image_u8: shape/dtype");
     const long total = dst->n * dst->h * dst->w;
@@ -451,8 +461,9 @@ extern "C" int fusg_to_image_u8(const fusg_tensor* x, const fusg_tensor* dst, vo
     FUSG_LAUNCH_CHECK("to_image_u8");
     return FUSG_OK;
 }
+extern "C" int fusg_to_image_u8(const fusg_tensor* x, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(to_image_u8_impl, stream, x, dst); }
 
-extern "C" int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_tensor* mask, const fusg_tensor* dst,
+static int merge_u8_impl(const fusg_tensor* out, const fusg_tensor* img, const fusg_tensor* mask, const fusg_tensor* dst,
                              void* stream) {
     FUSG_CHECK(out && img && mask && dst && out->data && img->data && mask->data && dst->data && dst->dtype == FUSG_U8 &&
                same_shape(*out, *img) && same_shape(*out, *dst) && same_nhw(*mask, *dst) && mask->c == 1, "merge_u8: shapes");
@@ -462,3 +473,4 @@ extern "C" int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, con
     FUSG_LAUNCH_CHECK("merge_u8");
     return FUSG_OK;
 }
+extern "C" int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_tensor* mask, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(merge_u8_impl, stream, out, img, mask, dst); }

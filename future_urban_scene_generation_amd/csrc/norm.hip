@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void ln_finalize_slots_kernel(const float* __
 
 using namespace fusg;
 
-extern "C" int fusg_in_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+static int in_finalize_slots_impl(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
                                       float* scale, float* shift, void* stream) {
     FUSG_CHECK(slots && scale && shift && batch >= 1 && nslots >= 1 && channels >= 1, "in_finalize_slots: bad arguments");
     hipLaunchKernelGGL(in_finalize_slots_kernel, dim3((channels + 15) / 16, batch), dim3(256), 0, (hipStream_t)stream, slots,
@@ -210,8 +210,9 @@ extern "C" int fusg_in_finalize_slots(const float* slots, int32_t batch, int32_t
     FUSG_LAUNCH_CHECK("in_finalize_slots");
     return FUSG_OK;
 }
+extern "C" int fusg_in_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps, float* scale, float* shift, void* stream) { return fusg::plan_dispatch(in_finalize_slots_impl, stream, slots, batch, nslots, channels, eps, scale, shift); }
 
-extern "C" int fusg_ln_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
+static int ln_finalize_slots_impl(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps,
                                       const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
     FUSG_CHECK(slots && scale && shift && gamma && beta && batch >= 1 && nslots >= 1 && channels >= 1 &&
                (long)nslots * channels * 32 > 1, "ln_finalize_slots: bad arguments");
@@ -220,8 +221,9 @@ extern "C" int fusg_ln_finalize_slots(const float* slots, int32_t batch, int32_t
     FUSG_LAUNCH_CHECK("ln_finalize_slots");
     return FUSG_OK;
 }
+extern "C" int fusg_ln_finalize_slots(const float* slots, int32_t batch, int32_t nslots, int32_t channels, float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) { return fusg::plan_dispatch(ln_finalize_slots_impl, stream, slots, batch, nslots, channels, eps, gamma, beta, scale, shift); }
 
-extern "C" int fusg_chan_stats(const fusg_tensor* x, float* partial, int32_t nchunk, void* stream) {
+static int chan_stats_impl(const fusg_tensor* x, float* partial, int32_t nchunk, void* stream) {
     FUSG_CHECK(x && is_nhwc(*x) && x->c % 4 == 0, "chan_stats: x must be NHWC-physical with C%%4==0");
     FUSG_CHECK(partial && nchunk >= 1 && nchunk <= 4096, "chan_stats: bad partial/nchunk");
     const long HW = x->h * x->w;
@@ -233,8 +235,9 @@ extern "C" int fusg_chan_stats(const fusg_tensor* x, float* partial, int32_t nch
     FUSG_LAUNCH_CHECK("chan_stats");
     return FUSG_OK;
 }
+extern "C" int fusg_chan_stats(const fusg_tensor* x, float* partial, int32_t nchunk, void* stream) { return fusg::plan_dispatch(chan_stats_impl, stream, x, partial, nchunk); }
 
-extern "C" int fusg_in_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, float* scale,
+static int in_finalize_impl(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, float* scale,
                                 float* shift, void* stream) {
     FUSG_CHECK(x && is_nhwc(*x) && partial && scale && shift && nchunk >= 1, "in_finalize: bad arguments");
     const int total = (int)(x->n * x->c);
@@ -244,8 +247,9 @@ extern "C" int fusg_in_finalize(const fusg_tensor* x, const float* partial, int3
     FUSG_LAUNCH_CHECK("in_finalize");
     return FUSG_OK;
 }
+extern "C" int fusg_in_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, float* scale, float* shift, void* stream) { return fusg::plan_dispatch(in_finalize_impl, stream, x, partial, nchunk, eps, scale, shift); }
 
-extern "C" int fusg_ln_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, const float* gamma,
+static int ln_finalize_impl(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, const float* gamma,
                                 const float* beta, float* scale, float* shift, void* stream) {
     FUSG_CHECK(x && is_nhwc(*x) && partial && scale && shift && gamma && beta && nchunk >= 1, "ln_finalize: bad arguments");
     FUSG_CHECK(x->c * x->h * x->w > 1, "ln_finalize: needs more than one element per sample");
@@ -254,3 +258,4 @@ extern "C" int fusg_ln_finalize(const fusg_tensor* x, const float* partial, int3
     FUSG_LAUNCH_CHECK("ln_finalize");
     return FUSG_OK;
 }
+extern "C" int fusg_ln_finalize(const fusg_tensor* x, const float* partial, int32_t nchunk, float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) { return fusg::plan_dispatch(ln_finalize_impl, stream, x, partial, nchunk, eps, gamma, beta, scale, shift); }

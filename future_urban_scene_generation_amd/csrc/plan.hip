@@ -1,0 +1,151 @@
+// Recorded passes: one call replays a whole crop pass.
+//
+// The reference calls its networks at batch 1 (trajectory_inference.py:55,65), where a pass of this library is ~370
+// launches of a few microseconds each and the Python / ctypes issue path (4.4 ms per pass) - not the GPU - sets the
+// latency.  A fusg_plan records the launch sequence of one pass ONCE: while recording is on for the calling thread,
+// every launching entry point appends a closure of itself (descriptors copied by value, stream remembered) before it
+// executes (common.h: plan_dispatch), and the host adds the few things that are not libfusg launches: cross-stream
+// dependencies (record an event on one stream, wait for it on another) and host-to-device copies of per-pass data
+// (the VUnet's CPU-drawn noise, from a ring of pinned buffers).  fusg_plan_run then re-issues the sequence in order on the recorded streams.
+//
+// This is deliberately not a hipGraph: on ROCm 7.2 a captured multi-stream pass replays 40-60 % SLOWER than eager
+// launching (measured in round 1, DESIGN.md §7: graph nodes are dispatched through one queue with a barrier per node,
+// so the small launches of the three branches no longer overlap).  A plan keeps eager semantics - same streams, same
+// priorities, same overlap - and only removes the interpreter from the issue path.
+//
+// Contract: every device pointer a recorded call used must stay valid and keep its meaning until the plan is destroyed
+// (the Python side records inside a private torch memory pool and keeps the pool), inputs are refreshed in place.
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+struct fusg_plan {
+    struct Op {
+        int kind;                                   // 0 launch closure, 1 record event, 2 wait event, 3 h2d copy
+        hipStream_t stream;
+        std::function<int(hipStream_t)> fn;
+        hipEvent_t ev;
+        void* dst; const char* src; size_t bytes, slot_stride;
+        int ev0;                                    // h2d: index of this op's first per-slot event in `events`
+    };
+    std::vector<Op> ops;
+    std::vector<hipEvent_t> events;                 // owned
+    std::vector<int> h2d_ops;                       // indices of the h2d ops
+    int nslots = 0;                                 // ring depth of the pinned h2d sources (same for all h2d ops)
+    long runs = 0;                                  // passes issued so far (the recording counts as one)
+};
+
+namespace fusg {
+
+static thread_local fusg_plan* g_rec = nullptr;
+
+bool plan_recording() { return g_rec != nullptr; }
+
+void plan_append(hipStream_t stream, std::function<int(hipStream_t)> fn) {
+    if (!g_rec) return;
+    fusg_plan::Op op{};
+    op.kind = 0; op.stream = stream; op.fn = std::move(fn);
+    g_rec->ops.push_back(std::move(op));
+}
+
+}  // namespace fusg
+
+using namespace fusg;
+
+extern "C" fusg_plan* fusg_plan_create(void) { return new fusg_plan(); }
+
+extern "C" void fusg_plan_destroy(fusg_plan* p) {
+    if (!p) return;
+    if (g_rec == p) g_rec = nullptr;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    delete p;
+}
+
+extern "C" int fusg_plan_begin(fusg_plan* p) {
+    FUSG_CHECK(p && !g_rec, "plan_begin: null plan or a recording is already open on this thread");
+    FUSG_CHECK(p->ops.empty(), "plan_begin: the plan already holds a recording");
+    g_rec = p;
+    return FUSG_OK;
+}
+
+extern "C" int fusg_plan_end(fusg_plan* p) {
+    FUSG_CHECK(p && g_rec == p, "plan_end: this plan is not recording on this thread");
+    g_rec = nullptr;
+    p->runs = 1;                                    // the recording pass used slot 0
+    return FUSG_OK;
+}
+
+// `waiter` must not run past this point before the work issued so far on `signaller` has finished.  Also performs the
+// synchronisation now (the recording pass is a real pass).
+extern "C" int fusg_plan_add_dependency(fusg_plan* p, void* waiter, void* signaller) {
+    FUSG_CHECK(p && g_rec == p, "plan_add_dependency: plan is not recording");
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan_add_dependency: hipEventCreate failed"); return FUSG_ERR_LAUNCH; }
+    p->events.push_back(ev);
+    fusg_plan::Op rec{}; rec.kind = 1; rec.stream = (hipStream_t)signaller; rec.ev = ev;
+    fusg_plan::Op wai{}; wai.kind = 2; wai.stream = (hipStream_t)waiter; wai.ev = ev;
+    p->ops.push_back(rec);
+    p->ops.push_back(wai);
+    if (hipEventRecord(ev, (hipStream_t)signaller) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) {
+        set_error("plan_add_dependency: event record / wait failed");
+        return FUSG_ERR_LAUNCH;
+    }
+    return FUSG_OK;
+}
+
+// Per-pass host data (pinned) -> device, recorded as an asynchronous copy on `stream`.  The source is a ring of
+// `nslots` buffers `slot_stride` bytes apart: run r copies from slot r % nslots, so the host can fill the next slot
+// while earlier passes are still queued (fusg_plan_next_slot tells which, and waits until that slot's last copy has
+// executed).  Also copies now, from slot 0 (the recording is run 0).
+extern "C" int fusg_plan_add_h2d(fusg_plan* p, void* dst, const void* src, int64_t bytes, int32_t nslots, int64_t slot_stride, void* stream) {
+    FUSG_CHECK(p && g_rec == p && dst && src && bytes > 0 && nslots >= 1 && slot_stride >= bytes, "plan_add_h2d: plan is not recording / bad arguments");
+    FUSG_CHECK(p->nslots == 0 || p->nslots == nslots, "plan_add_h2d: all copies of a plan use the same ring depth (%d)", p->nslots);
+    p->nslots = nslots;
+    fusg_plan::Op op{};
+    op.kind = 3; op.stream = (hipStream_t)stream; op.dst = dst; op.src = (const char*)src; op.bytes = (size_t)bytes;
+    op.slot_stride = (size_t)slot_stride; op.ev0 = (int)p->events.size();
+    for (int i = 0; i < nslots; ++i) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("plan_add_h2d: hipEventCreate failed"); return FUSG_ERR_LAUNCH; }
+        p->events.push_back(ev);
+    }
+    p->h2d_ops.push_back((int)p->ops.size());
+    p->ops.push_back(op);
+    if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipEventRecord(p->events[op.ev0], (hipStream_t)stream) != hipSuccess) {
+        set_error("plan_add_h2d: copy failed");
+        return FUSG_ERR_LAUNCH;
+    }
+    return FUSG_OK;
+}
+
+// Slot of the pinned rings that the NEXT fusg_plan_run will copy from; returns once the copies that last used that
+// slot (nslots passes ago) have executed, so that the host may overwrite it.  -1 on error.
+extern "C" int fusg_plan_next_slot(fusg_plan* p) {
+    if (!p || g_rec) { set_error("plan_next_slot: null plan or still recording"); return -1; }
+    if (p->nslots == 0) return 0;
+    const int slot = (int)(p->runs % p->nslots);
+    if (p->runs >= p->nslots)
+        for (int oi : p->h2d_ops)
+            if (hipEventSynchronize(p->events[p->ops[oi].ev0 + slot]) != hipSuccess) { set_error("plan_next_slot: event sync failed"); return -1; }
+    return slot;
+}
+
+extern "C" int64_t fusg_plan_size(const fusg_plan* p) { return p ? (int64_t)p->ops.size() : -1; }
+
+extern "C" int fusg_plan_run(fusg_plan* p) {
+    FUSG_CHECK(p && !g_rec, "plan_run: null plan or a recording is open on this thread");
+    const int slot = p->nslots ? (int)(p->runs % p->nslots) : 0;
+    for (fusg_plan::Op& op : p->ops) {
+        switch (op.kind) {
+            case 0: { const int rc = op.fn(op.stream); if (rc != FUSG_OK) return rc; break; }
+            case 1: if (hipEventRecord(op.ev, op.stream) != hipSuccess) { set_error("plan_run: event record failed"); return FUSG_ERR_LAUNCH; } break;
+            case 2: if (hipStreamWaitEvent(op.stream, op.ev, 0) != hipSuccess) { set_error("plan_run: stream wait failed"); return FUSG_ERR_LAUNCH; } break;
+            default:
+                if (hipMemcpyAsync(op.dst, op.src + (size_t)slot * op.slot_stride, op.bytes, hipMemcpyHostToDevice, op.stream) != hipSuccess ||
+                    hipEventRecord(p->events[op.ev0 + slot], op.stream) != hipSuccess) { set_error("plan_run: h2d copy failed"); return FUSG_ERR_LAUNCH; }
+        }
+    }
+    p->runs += 1;
+    return FUSG_OK;
+}

@@ -119,6 +119,32 @@ def stream_ptr() -> int:
 
 _NO_TENSOR = L.Tensor()
 
+# ---- recorded passes (include/fusg.h, fusg_plan) -----------------------------------------------------------------
+# While `RECORDER` is set, the calling thread is recording a pass into a fusg_plan (pipeline.CompiledPass): libfusg
+# remembers every launch by itself; the Python side only has to route the two things that are not libfusg launches
+# through the recorder - cross-stream dependencies and the host-to-device copies of per-pass host data.
+RECORDER = None
+
+
+class PlanRecorder:
+    def __init__(self):
+        self.handle = L.lib().fusg_plan_create()
+        self.noise_slots = []                  # [(pinned host buffer, [shape, ...])] in draw order
+        self.keep = []                         # tensors the recorded launches point into beyond the memory pool
+
+    def dependency(self, waiter: int, signaller: int) -> None:
+        L.check(L.lib().fusg_plan_add_dependency(self.handle, waiter, signaller), "plan_add_dependency")
+
+    NSLOTS = 4                                 # ring depth of the pinned sources: the host may run this many passes ahead
+
+    def h2d(self, dst: torch.Tensor, src_ring: torch.Tensor) -> None:
+        """src_ring: pinned [NSLOTS, n] - slot 0 holds the data of the recording pass."""
+        assert src_ring.is_pinned() and dst.is_cuda and src_ring.dim() == 2 and src_ring.shape[0] == self.NSLOTS
+        nbytes = dst.numel() * dst.element_size()
+        assert nbytes == src_ring.shape[1] * src_ring.element_size()
+        L.check(L.lib().fusg_plan_add_h2d(self.handle, dst.data_ptr(), src_ring.data_ptr(), nbytes, self.NSLOTS,
+                                          src_ring.stride(0) * src_ring.element_size(), stream_ptr()), "plan_add_h2d")
+
 
 def desc(t: Optional[torch.Tensor]) -> L.Tensor:
     """fusg_tensor for a 4-D torch tensor (or an absent tensor: a shared all-zero struct, never written to)."""

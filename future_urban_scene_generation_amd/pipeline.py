@@ -106,19 +106,31 @@ class VehiclePipeline:
             for _, j in jobs:
                 out.update(j())
             return out
+        from . import ops
+        rec = ops.RECORDER                                  # recording a fusg_plan: dependencies go through it
         main = torch.cuda.current_stream(self.device)
         pool = self.__dict__.setdefault("_streams", {})
-        ready = torch.cuda.Event()
-        ready.record(main)
+        streams = []
+        for name, _ in jobs[1:]:
+            st = pool.get(name)
+            if st is None:
+                st = pool[name] = torch.cuda.Stream(device=self.device, priority=-1 if name in self.HIGH_PRIORITY else 0)
+            streams.append(st)
+        # fork: the side branches may start as soon as what is on the caller's stream NOW is done (not after branch 0)
+        if rec is None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in streams:
+                st.wait_event(ready)
+        else:
+            for st in streams:
+                rec.dependency(st.cuda_stream, main.cuda_stream)
         used = []
         for i, (name, j) in enumerate(jobs):
             if i == 0:
                 out.update(j())
                 continue
-            st = pool.get(name)
-            if st is None:
-                st = pool[name] = torch.cuda.Stream(device=self.device, priority=-1 if name in self.HIGH_PRIORITY else 0)
-            st.wait_event(ready)
+            st = streams[i - 1]
             with torch.cuda.stream(st):
                 res = j()
             for t in res.values():
@@ -126,8 +138,17 @@ class VehiclePipeline:
             out.update(res)
             used.append(st)
         for st in used:
-            main.wait_stream(st)
+            if rec is None:
+                main.wait_stream(st)
+            else:
+                rec.dependency(main.cuda_stream, st.cuda_stream)
         return out
+
+    def compile(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> "CompiledPass":
+        """Record one crop pass for inputs of `batch`'s shapes into a fusg_plan and return the object that replays it:
+        `compiled.run(batch, vehicle_seeds)` gives what `self.run` gives, with one library call instead of ~370 (the
+        reference's batch-1 call pattern is bound by the interpreter, not by the GPU)."""
+        return CompiledPass(self, batch, vehicle_seeds)
 
     # Range guard of the split-fp16 contraction (ops.py): the networks' own per-call checks are deferred while a pass
     # is being issued (they would synchronise the host once per network and undo the stream overlap); the pass is
@@ -249,6 +270,87 @@ class VehiclePipeline:
             return {"vunet_u8": ops.to_image_u8(xt).view(V, F, R, R, 3)}
 
         return self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)])
+
+
+class CompiledPass:
+    """A recorded crop pass of a VehiclePipeline (include/fusg.h, fusg_plan): fixed input shapes, persistent input /
+    intermediate / output buffers (a private torch memory pool that lives as long as this object), per-pass host data
+    (the VUnet's CPU-drawn sampler noise: same generator, order and shapes as the reference) refreshed before every
+    replay.  The returned tensors are the plan's output buffers: the next `run` overwrites them."""
+
+    def __init__(self, pipe: "VehiclePipeline", batch: Dict[str, torch.Tensor], vehicle_seeds=None):
+        from . import _lib as L
+        from . import ops
+        self.pipe, self.device = pipe, pipe.device
+        self.precision = ops.PRECISION                                        # recorded into every conv descriptor
+        self.keys = sorted(batch.keys())
+        with torch.cuda.device(self.device):
+            pipe.run(batch, vehicle_seeds=vehicle_seeds, check=None)          # warm-up: weight upload, workspaces, streams
+            torch.cuda.synchronize(self.device)
+            self.stream = torch.cuda.current_stream(self.device)
+            self.pool = torch.cuda.MemPool()
+            self.rec = ops.PlanRecorder()
+            with torch.cuda.use_mem_pool(self.pool, device=self.device):
+                self.inputs = {k: torch.empty_like(batch[k]).copy_(batch[k]) for k in self.keys}
+                L.check(L.lib().fusg_plan_begin(self.rec.handle), "plan_begin")
+                ops.RECORDER = self.rec
+                try:
+                    with ops.defer_range_check():
+                        self.outputs = pipe._run(self.inputs, vehicle_seeds)
+                finally:
+                    ops.RECORDER = None
+                    L.check(L.lib().fusg_plan_end(self.rec.handle), "plan_end")
+            torch.cuda.synchronize(self.device)
+        self.size = int(L.lib().fusg_plan_size(self.rec.handle))
+
+    def __del__(self):
+        try:
+            from . import _lib as L
+            torch.cuda.synchronize(self.device)
+            L.lib().fusg_plan_destroy(self.rec.handle)
+        except Exception:                                                     # interpreter shutdown
+            pass
+
+    def _issue(self, batch, vehicle_seeds):
+        from . import _lib as L
+        for k in self.keys:
+            src = batch[k]
+            if src.data_ptr() != self.inputs[k].data_ptr():
+                if src.shape != self.inputs[k].shape:
+                    raise ValueError(f"CompiledPass: input '{k}' has shape {tuple(src.shape)}, recorded {tuple(self.inputs[k].shape)}")
+                self.inputs[k].copy_(src, non_blocking=True)
+        lib = L.lib()
+        slot = lib.fusg_plan_next_slot(self.rec.handle)                       # which pinned ring slot this run reads
+        if slot < 0:
+            L.check(-1, "plan_next_slot")
+        vu = self.pipe.vunet
+        vu.set_vehicle_seeds(vehicle_seeds)
+        gens = vu.__dict__.get("_vehicle_gens")
+        for ring, shapes in self.rec.noise_slots:                             # the reference's draw order
+            vu._fill_noise(ring[slot], shapes, gens)
+        L.check(lib.fusg_plan_run(self.rec.handle), "plan_run")
+        return self.outputs
+
+    def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
+            check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
+        """Same contract as VehiclePipeline.run (incl. the range guard: on a raised status the pass is redone eagerly in
+        exact fp32).  Must be called with the stream that was current at compile time."""
+        from . import ops
+        with torch.cuda.device(self.device):
+            if torch.cuda.current_stream(self.device) != self.stream:
+                raise RuntimeError("CompiledPass.run: the current stream differs from the one the pass was recorded on")
+            if ops.PRECISION != self.precision:
+                raise RuntimeError(f"CompiledPass.run: recorded with precision {self.precision}, now {ops.PRECISION}")
+            rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync" and ops.PRECISION == "f16x3") else None
+            out = self._issue(batch, vehicle_seeds)
+            if ops.PRECISION != "f16x3" or check != "sync":
+                return out
+            if not ops.range_exceeded(self.device):
+                return out
+            if rng is not None:
+                torch.set_rng_state(rng)
+            with ops.defer_range_check(), ops.precision("f32"):
+                return self.pipe._run(batch, vehicle_seeds)
 
 
 def synth_clip(vehicles: int, frames: int, res: int, device, seed: int = 0) -> Dict[str, torch.Tensor]:

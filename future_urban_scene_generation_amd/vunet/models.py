@@ -241,6 +241,16 @@ class Vunet_fix_res(FusedNet):
         synchronous ones (each of which would stall the launch queue).  A small ring of staging
         buffers, guarded by events, keeps a buffer alive until its copy has executed."""
         total = sum(int(torch.Size(s).numel()) for s in shapes)
+        if ops.RECORDER is not None:
+            # recorded pass: this call site gets its own pinned source and device destination for the life of the
+            # plan; the copy becomes a plan operation and the host refills the source before every replay
+            ring = torch.empty((ops.RECORDER.NSLOTS, total), dtype=torch.float32, pin_memory=True)
+            views = self._fill_noise(ring[0], shapes, self.__dict__.get("_vehicle_gens"))
+            dev_buf = torch.empty(total, dtype=torch.float32, device=device)
+            ops.RECORDER.h2d(dev_buf, ring)
+            ops.RECORDER.noise_slots.append((ring, [tuple(s) for s in shapes]))
+            ops.RECORDER.keep.append(dev_buf)
+            return [dev_buf[o:o + n].view(*s) for o, n, s in views]
         ring = self.__dict__.setdefault("_noise_ring", [])
         slot = self.__dict__.get("_noise_slot", 0)
         self.__dict__["_noise_slot"] = (slot + 1) % 4

@@ -282,6 +282,29 @@ int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream
  * the pixel lies outside that rectangle; masks u8 [V, 1, H, W] (non-zero = paste), geom as in fusg_icn_inputs. */
 int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream);
 
+/* ---- recorded passes ------------------------------------------------------------------------ */
+/* A fusg_plan records the launch sequence of one pass (every fusg_* launch made by the recording thread between
+ * fusg_plan_begin and fusg_plan_end, with its descriptors copied and its stream remembered; the calls also execute)
+ * and replays it with ONE call - the batch-1 call pattern of the reference (trajectory_inference.py:55,65) is bound by
+ * the interpreter's ~12 us per launch, not by the GPU.  Not a hipGraph: replay issues the same launches on the same
+ * streams (overlap between the branches of a pass is kept; a captured graph serialises them on ROCm 7.2).
+ * Every device pointer used while recording must stay valid, with the same meaning, until fusg_plan_destroy. */
+typedef struct fusg_plan fusg_plan;
+fusg_plan* fusg_plan_create(void);
+void       fusg_plan_destroy(fusg_plan* p);
+int        fusg_plan_begin(fusg_plan* p);         /* start recording on the calling thread */
+int        fusg_plan_end(fusg_plan* p);
+/* `waiter` (hipStream_t) may not pass this point before the work issued so far on `signaller` is done. */
+int        fusg_plan_add_dependency(fusg_plan* p, void* waiter, void* signaller);
+/* asynchronous copy of `bytes` from pinned host memory to the device on `stream`, repeated by every run.  `src` is a
+ * ring of `nslots` buffers `slot_stride` bytes apart; run r reads slot r % nslots (the recording is run 0).  Before a
+ * run, fusg_plan_next_slot() returns the slot that run will read and waits until the copies that last read it have
+ * executed: fill that slot, then call fusg_plan_run. */
+int        fusg_plan_add_h2d(fusg_plan* p, void* dst, const void* src, int64_t bytes, int32_t nslots, int64_t slot_stride, void* stream);
+int        fusg_plan_next_slot(fusg_plan* p);
+int64_t    fusg_plan_size(const fusg_plan* p);    /* recorded operations */
+int        fusg_plan_run(fusg_plan* p);           /* re-issue the recording; asynchronous like the launches themselves */
+
 /* ---- misc ----------------------------------------------------------------------------------- */
 
 int         fusg_version(void);

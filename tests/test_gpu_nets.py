@@ -432,3 +432,37 @@ def test_edgeconnect_checkpoint_roundtrip(tmp_path):
     before = {k: v.clone() for k, v in em.generator.state_dict().items()}
     em.load()                                                     # no file: the initial weights stay
     assert all(torch.equal(v, em.generator.state_dict()[k]) for k, v in before.items())
+
+
+def test_compiled_pass_replays_the_eager_pass(precision):
+    """A recorded pass (fusg_plan, pipeline.CompiledPass) gives bit for bit what the eager pass gives - on the inputs it
+    was recorded with, on new inputs, with per-vehicle seeds and with the reference's global generator - and keeps the
+    range guard."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    B, R = 2, 128
+    pipe = VehiclePipeline(DEV, inpaint=(precision == "f32"))                 # (one precision also covers EdgeConnect)
+    b0 = synth_batch(B, R, DEV, inpaint=pipe.inpaint, seed=0)
+    b1 = synth_batch(B, R, DEV, inpaint=pipe.inpaint, seed=1)
+    cp = pipe.compile(b0, vehicle_seeds=[7, 8])
+    assert cp.size > 200 and len(cp.rec.noise_slots) == 2
+    for batch, seeds in ((b0, [7, 8]), (b1, [9, 10]), (b0, [7, 8])):
+        want = {k: v.clone() for k, v in pipe.run(batch, vehicle_seeds=seeds).items()}
+        got = cp.run(batch, vehicle_seeds=seeds)
+        assert set(got) == set(want)
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    torch.manual_seed(4)
+    want = {k: v.clone() for k, v in pipe.run(b1).items()}
+    torch.manual_seed(4)
+    got = cp.run(b1)
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    with pytest.raises(ValueError):
+        cp.run({k: v[:1] for k, v in b0.items()})
+    if precision == "f16x3":
+        bad = {k: v.clone() for k, v in b1.items()}
+        bad["vu_x"][0, 0, 3, 3] = 5e4
+        got = cp.run(bad, vehicle_seeds=[1, 2])
+        with ops.precision("f32"):
+            want = pipe.run(bad, vehicle_seeds=[1, 2])
+        assert all(torch.equal(got[k], want[k]) for k in want)
+        assert not ops.range_exceeded(DEV)
