@@ -47,6 +47,16 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("wscale", C.c_void_p), ("status", C.c_void_p)]
 
 
+class PackSpec(C.Structure):            # fusg_pack_spec
+    _fields_ = [(n, C.c_int32) for n in ("cout", "cin", "kh", "kw", "c0", "stride", "pad", "dil", "upsample", "cin_pad")]
+
+
+class PackSizes(C.Structure):           # fusg_pack_sizes
+    _fields_ = [("cout_pad", C.c_int32), ("k_pad", C.c_int32), ("c0k", C.c_int32), ("c1k", C.c_int32),
+                ("wfrag_order", C.c_int32), ("_pad", C.c_int32), ("wpack_floats", C.c_int64), ("ktab_ints", C.c_int64),
+                ("wpack_h_halves", C.c_int64), ("wfrag_halves", C.c_int64)]
+
+
 # enums (include/fusg.h)
 F32, U8, I32 = 0, 1, 2
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
@@ -93,6 +103,8 @@ _SIGS = {
     "fusg_plan_next_slot": (C.c_int, [C.c_void_p]),
     "fusg_plan_size": (C.c_int64, [C.c_void_p]),
     "fusg_plan_run": (C.c_int, [C.c_void_p]),
+    "fusg_pack_conv_sizes": (C.c_int, [C.POINTER(PackSpec), C.POINTER(PackSizes)]),
+    "fusg_pack_conv_weights": (C.c_int, [C.POINTER(PackSpec)] + [C.c_void_p] * 8),
     "fusg_version": (C.c_int, []),
     "fusg_last_error": (C.c_char_p, []),
     "fusg_last_conv_kernel": (C.c_int, []),

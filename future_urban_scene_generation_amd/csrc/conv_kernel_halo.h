@@ -68,8 +68,17 @@ __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, in
     o.r1 = b * p.r1n + Y * p.r1h + X * p.r1w;
 }
 
+// waves per SIMD the register allocator is asked to allow: the 128-column tile needs ~230 VGPRs (2), the narrower
+// tiles far fewer - and their launches (few output channels: VUnet 32 / 64-channel layers, hourglass 1x1) are bound by
+// memory latency, so more resident workgroups per CU is what they need
+#ifdef FUSG_HALO_OCC
+constexpr int halo_waves(int tm, int tn) { return tm * tn == 1 ? 4 : (tm * tn == 2 ? 3 : FUSG_HALO_WAVES); }
+#else
+constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
+#endif
+
 template <int TM, int TN, int WM, int WN, int PK, int NI>
-__global__ __launch_bounds__(256, FUSG_HALO_WAVES) void conv_halo_h3(const HaloK hk) {
+__global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
     constexpr int LOGC = 3;

@@ -195,3 +195,63 @@ def test_f16x3_split_is_fp32_class():
             e1 = ((a.half().double() @ w.half().double() - exact).abs() / scale).max().item()
             e32 = (((a @ w).double() - exact).abs() / scale).max().item()
             assert e3 < 1e-7 and e3 < e1 / 200, (sa, sw, e3, e1, e32)       # ~2^-24 at every scale vs fp16's ~2^-11
+
+
+# ---- the C-ABI packer (csrc/pack.hip) against pack.py, bit for bit (host code: runs without a GPU) ---------------
+C_PACK_CASES = [  # cout, cin, k, c0, stride, pad, dil, upsample, cin_pad  -> expected wfrag_order
+    (128, 128, 3, 128, 1, 1, 1, 0, 4, 0),        # halo kernel, plain order
+    (256, 256, 3, 256, 1, 2, 2, 0, 4, 0),        # dilated
+    (32, 96, 3, 32, 1, 1, 1, 0, 4, 0),           # two sources (32 + 64): VUnet Residual
+    (128, 64, 4, 64, 2, 1, 1, 0, 4, 1),          # stride-2 k4: parity-quadrant order
+    (128, 128, 3, 128, 2, 1, 1, 0, 4, 1),        # stride-2 k3
+    (64, 21, 7, 21, 1, 3, 1, 0, 4, 2),           # ICN stem: tap-unit kernel (24 K-channels, unit 8)
+    (64, 3, 7, 3, 2, 3, 1, 0, 4, 2),             # hourglass stem (4 K-channels, unit 4)
+    (12, 256, 1, 256, 1, 0, 1, 0, 4, 0),         # score conv: cout padded to 32
+    (40, 12, 3, 12, 1, 1, 1, 0, 4, 2),           # 12 channels, 3x3: tap-unit kernel
+    (40, 44, 3, 44, 1, 1, 1, 0, 4, -1),          # generic gather only
+    (64, 128, 5, 128, 1, 2, 1, 1, 4, 0),         # 5x5 behind the fused upsample
+    (64, 21, 7, 21, 1, 3, 1, 0, 32, 0),          # few channels padded to 32 for the halo kernel
+]
+
+
+@pytest.mark.parametrize("cout,cin,k,c0,stride,pad,dil,ups,cin_pad,order", C_PACK_CASES)
+def test_c_abi_packer_matches_pack_py(cout, cin, k, c0, stride, pad, dil, ups, cin_pad, order):
+    import ctypes as C
+    import numpy as np
+    from future_urban_scene_generation_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(cout * 131 + cin)
+    w = torch.randn(cout, cin, k, k, generator=g) * torch.logspace(-3, 1, cout).view(-1, 1, 1, 1)     # per-channel scales
+    b = torch.randn(cout, generator=g)
+    plan = pack.pack_conv(w, b, c_split=(c0, cin - c0) if c0 < cin else None, stride=stride, pad=pad, dil=dil,
+                          upsample=ups, cin_pad=cin_pad)
+    wsplit, wscale = pack.split_f16x3(plan.wpack)
+    spec = L.PackSpec(cout=cout, cin=cin, kh=k, kw=k, c0=c0, stride=stride, pad=pad, dil=dil, upsample=ups, cin_pad=cin_pad)
+    sz = L.PackSizes()
+    L.check(lib.fusg_pack_conv_sizes(C.byref(spec), C.byref(sz)), "pack_conv_sizes")
+    assert (sz.cout_pad, sz.k_pad, sz.c0k, sz.c1k) == (plan.cout_pad, plan.k_pad, plan.c0k, plan.c1k)
+    assert sz.wfrag_order == order
+    wpack = np.empty(sz.wpack_floats, np.float32)
+    ktab = np.empty(sz.ktab_ints, np.int32)
+    bias = np.empty(sz.cout_pad, np.float32)
+    wh = np.empty(sz.wpack_h_halves, np.uint16)
+    wsc = np.empty(sz.cout_pad, np.float32)
+    wfrag = np.empty(max(1, sz.wfrag_halves), np.uint16)
+    wc, bc = w.contiguous().numpy(), b.numpy()
+    L.check(lib.fusg_pack_conv_weights(C.byref(spec), wc.ctypes.data, bc.ctypes.data, wpack.ctypes.data, ktab.ctypes.data,
+                                       bias.ctypes.data, wh.ctypes.data, wsc.ctypes.data,
+                                       wfrag.ctypes.data if sz.wfrag_halves else None), "pack_conv_weights")
+    assert np.array_equal(wpack.reshape(plan.cout_pad, plan.k_pad), plan.wpack[0].numpy())
+    assert np.array_equal(ktab.reshape(-1, 2), plan.ktab[0].numpy())
+    assert np.array_equal(bias, plan.bias.numpy()) and np.array_equal(wsc, wscale.numpy())
+    assert np.array_equal(wh, wsplit[0].view(torch.int16).numpy().astype(np.uint16).reshape(-1))
+    # the fragment-order copy, as ConvPlan.to() builds it
+    frag = pack.frag_f16x3(wsplit, plan)
+    if frag is not None and plan.s2d_ok():
+        frag = frag[pack.s2d_tap_order(plan.kh)].contiguous()
+    if frag is None and plan.tapunit_ok():
+        frag = pack.frag_tapunit(wsplit, plan)
+    assert (frag is None) == (order < 0)
+    if frag is not None:
+        assert (1 if plan.s2d_ok() else (2 if plan.tapunit_ok() else 0)) == order
+        assert np.array_equal(wfrag, frag.contiguous().view(torch.int16).numpy().astype(np.uint16).reshape(-1))

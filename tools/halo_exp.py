@@ -110,6 +110,12 @@ def main():
         ("hg 256->128 1x1 @64 affine", 32, 256, 128, 1, 0, 64, L.PRE_AFFINE_RELU, 0, 1),
         ("ec 256->256 3x3 d2 @64 affine", 32, 256, 256, 3, 2, 64, L.PRE_AFFINE_RELU, 0, 2),
         ("vu 64->32 3x3 @256 elu", 32, 64, 32, 3, 1, 256, L.PRE_ELU, 0, 1),
+        ("vu 32->32 3x3 @256 elu", 32, 32, 32, 3, 1, 256, L.PRE_ELU, 0, 1),
+        ("vu 32->32 1x1 @256 elu", 32, 32, 32, 1, 0, 256, L.PRE_ELU, 0, 1),
+        ("vu 128->64 3x3 @64 elu", 32, 128, 64, 3, 1, 64, L.PRE_ELU, 0, 1),
+        ("hg 128->256 1x1 @64 affine", 32, 128, 256, 1, 0, 64, L.PRE_AFFINE_RELU, 0, 1),
+        ("hg 128->128 3x3 @32 affine", 32, 128, 128, 3, 1, 32, L.PRE_AFFINE_RELU, 0, 1),
+        ("hg 128->128 3x3 @16 affine", 32, 128, 128, 3, 1, 16, L.PRE_AFFINE_RELU, 0, 1),
     ]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = args[0] if args else None
