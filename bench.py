@@ -48,6 +48,8 @@ GFLOP_PER_CROP = {"hg": 17.95, "icn": 130.12, "vunet_first": 76.27, "edge": 96.1
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak (no sparsity)
 DTYPE = {"f32": "f32",
+         "bf16": "f32 tensors; halo-kernel conv layers of ICN / VUnet / EdgeConnect contract in single-pass bf16 MFMA (f32 accumulate), "
+                 "remaining layers and the whole hourglass in f16x3 (BASELINE configs[4]'s bf16 path; SSIM >= 0.999, keypoints exact)",
          "f16x3": "f32 tensors; conv contraction as 3 fp16 MFMA products of scaled (hi, lo) operand splits, f32 accumulate "
                   "(error vs fp64 <= the f32 MFMA kernel's, range-guarded; exact-f32 leg in precision_legs)"}
 
@@ -71,8 +73,9 @@ def parse_args():
     ap.add_argument("--replay", action="store_true",
                     help="issue each pass as ONE recorded-plan replay (fusg_plan) instead of ~370 launches from Python: "
                          "matters at small --batch, where the interpreter bounds the pass")
-    ap.add_argument("--precision", choices=["f16x3", "f32", "both"], default="both",
-                    help="which precision legs to time (default both; the headline is f16x3 when it ran)")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "bf16", "both", "all"], default="all",
+                    help="which precision legs to time (default all three; the headline is f16x3 when it ran, bf16 is the "
+                         "reduced-precision path of BASELINE configs[4] and never the headline of an fp32 configuration)")
     return ap.parse_args()
 
 
@@ -376,6 +379,10 @@ def main():
             if prec == "f32":
                 kern, peak, note = "fusg::conv_igemm_f32 (all tile instantiations)", PEAK_F32_MFMA_TFLOPS, \
                     "fp32 MFMA: 1 matrix FLOP per algorithmic FLOP"
+            elif prec == "bf16":
+                kern, peak, note = "fusg::conv_halo_h3<..., bf16> + f16x3 kernels for the rest", PEAK_F16_MFMA_TFLOPS, \
+                    ("single-pass bf16 on the halo-kernel layers: 1 matrix FLOP per algorithmic FLOP there (peak = dense bf16 MFMA "
+                     "2500 TFLOP/s); the hourglass and the non-halo layers still cost 3")
             else:
                 kern, peak, note = "fusg::conv_halo_h3 + conv_tapunit_h3 + conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
                     ("split-fp16: every fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh'); peak = dense "
@@ -408,7 +415,7 @@ def main():
             leg["power"] = power
         return leg
 
-    legs_wanted = ["f16x3", "f32"] if args.precision == "both" else [args.precision]
+    legs_wanted = {"both": ["f16x3", "f32"], "all": ["f16x3", "f32", "bf16"]}.get(args.precision, [args.precision])
     sampler = None
     if rank == 0 and world == 1:
         pr = torch.cuda.get_device_properties(local_rank)

@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("wfrag_order", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
                 ("tile_list", C.c_void_p), ("tile_count", C.c_int32), ("q_oy", C.c_int32), ("q_ox", C.c_int32),
                 ("stats_slots", C.c_int32),
-                ("wscale", C.c_void_p), ("status", C.c_void_p)]
+                ("wscale", C.c_void_p), ("status", C.c_void_p), ("wfrag_bf16", C.c_void_p)]
 
 
 class PackSpec(C.Structure):            # fusg_pack_spec
@@ -63,7 +63,7 @@ PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 PRE_NONE, PRE_RELU, PRE_ELU, PRE_AFFINE_RELU, PRE_AFFINE = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_TANH01 = 0, 1, 2, 3, 4
 STORE_NORMAL, STORE_D2S, STORE_S2D = 0, 1, 2
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_EMU_BF16, PREC_EMU_BF16X2, PREC_BF16 = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_128x32, TILE_64x64, TILE_64x128 = 0, 1, 2, 3, 4, 5
 
 _TP = C.POINTER(Tensor)

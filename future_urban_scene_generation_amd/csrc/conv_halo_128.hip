@@ -1,5 +1,5 @@
-// BN = 128 column tile of the halo-tiled split-fp16 convolution (see conv_kernel_halo.h).
+// BN = 128 column tile of the halo-tiled split-fp16 / bf16 convolution (see conv_kernel_halo.h).
 #include "conv_kernel_halo.h"
 namespace fusg {
-hipError_t launch_halo_128(const HaloK& k, dim3 grid, hipStream_t s, int pk) { return launch_halo<2,2,2,2>(k, grid, s, pk); }
+hipError_t launch_halo_128(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf16) { return launch_halo<2,2,2,2>(k, grid, s, pk, bf16); }
 }  // namespace fusg

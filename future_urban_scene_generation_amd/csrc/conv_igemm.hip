@@ -97,6 +97,9 @@ extern "C" int64_t fusg_conv2d_plan(fusg_conv_desc* d) { return plan_impl(d); }
 static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     fusg_conv_desc dd = *din;
     fusg_conv_desc* d = &dd;
+    // FUSG_PREC_BF16: single-pass bf16 on the halo kernel where the layer qualifies, F16X3 everywhere else
+    const bool want_bf16 = d->precision == FUSG_PREC_BF16;
+    if (want_bf16) d->precision = FUSG_PREC_F16X3;
     hipStream_t s = (hipStream_t)stream;
     const fusg_tensor& x0 = d->src0;
     FUSG_CHECK(is_nhwc(x0), "conv2d: src0 must be NHWC-physical f32 (sc=1, Cs%%4=0, 16B aligned)");
@@ -105,8 +108,8 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
         FUSG_CHECK(is_nhwc(d->src1) && same_nhw(x0, d->src1), "conv2d: src1 must be NHWC-physical with src0's n,h,w");
     }
     FUSG_CHECK(d->bias && d->ktab, "conv2d: bias/ktab missing");
-    FUSG_CHECK(d->precision == FUSG_PREC_F32 || d->precision == FUSG_PREC_F16X3, "conv2d: precision %d", d->precision);
-    if (d->precision == FUSG_PREC_F32) FUSG_CHECK(d->wpack, "conv2d: wpack missing");
+    FUSG_CHECK(d->precision >= FUSG_PREC_F32 && d->precision <= FUSG_PREC_EMU_BF16X2, "conv2d: precision %d", din->precision);
+    if (d->precision != FUSG_PREC_F16X3) FUSG_CHECK(d->wpack, "conv2d: wpack missing");
     else FUSG_CHECK(d->wpack_h && (((uintptr_t)d->wpack_h) & 15) == 0 && d->wscale && (((uintptr_t)d->wscale) & 15) == 0 && d->status,
                     "conv2d: F16X3 needs 16B-aligned wpack_h and wscale, and a status word");
     FUSG_CHECK((((uintptr_t)d->wpack) & 15) == 0 && (((uintptr_t)d->ktab) & 7) == 0, "conv2d: wpack/ktab misaligned");
@@ -194,6 +197,7 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
     k.wpack_h = (const _Float16*)d->wpack_h;
     if (d->precision == FUSG_PREC_F16X3) { k.wscale = d->wscale; k.status = d->status; }
+    k.round_bits = d->precision == FUSG_PREC_EMU_BF16 ? 8 : (d->precision == FUSG_PREC_EMU_BF16X2 ? 16 : 0);
     k.H = (int)x0.h; k.W = (int)x0.w; k.ups = d->upsample; k.Hv = k.H << k.ups; k.Wv = k.W << k.ups;
     k.Cs0 = (int)x0.sw; k.Cs1 = has1 ? (int)d->src1.sw : (int)x0.sw; k.C0 = d->c0k;
     k.K_pad = d->k_pad; k.nk = d->k_pad / BK; k.Cout = d->cout; k.Cout_pad = d->cout_pad;
@@ -346,9 +350,11 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
         }
         if (halo_fits(h.HH, h.HW)) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
-            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk) : bn == 64 ? launch_halo_64(h, hgrid, s, pk) : launch_halo_32(h, hgrid, s, pk);
+            const bool bf = want_bf16 && d->wfrag_bf16 != nullptr && (((uintptr_t)d->wfrag_bf16) & 15) == 0;
+            if (bf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
+            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk, bf) : bn == 64 ? launch_halo_64(h, hgrid, s, pk, bf) : launch_halo_32(h, hgrid, s, pk, bf);
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
-            note_conv_kernel(h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO);
+            note_conv_kernel(bf ? FUSG_CONV_HALO_BF16 : (h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO));
             prof_end(0, s);
             return FUSG_OK;
         }

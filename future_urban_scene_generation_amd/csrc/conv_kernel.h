@@ -56,6 +56,10 @@ struct ConvK {
                              // time (pack.split_f16x3); the epilogue computes acc * wscale[n] + bias[n].  NULL = 1.
     int* status;             // f16x3 path: set to 1 by any workgroup that stages an operand with |x| >= 2^15 (outside
                              // the range the fp16 split represents); the caller re-runs the pass in exact fp32
+    int round_bits;          // exact-fp32 kernel only, 0 = off: round every staged activation to this many significant bits
+                             // (8 = bf16, 16 = two bf16 pieces) - the numerics of a reduced-precision MFMA path emulated
+                             // on the fp32 matrix cores (products of such operands are exact in fp32), for the bf16
+                             // evidence of DESIGN.md / tests::test_reduced_precision_evidence; not a production path
     const float* zeros;      // 256 B of zeros in device memory: where the gather of a zero-padded pixel reads.  It
                              // comes in through the kernel arguments so that the selected pointer stays a GLOBAL
                              // one (a select against the address of a __device__ variable degrades the load to
@@ -356,6 +360,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
             const bool ok = (okmask >> i) & 1u;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
+            if (p.round_bits) {                                  // round to nearest even at `round_bits` significant bits
+                const int drop = 24 - p.round_bits;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float f = v[c];                        // (a scalar copy: __builtin_bit_cast of a vector ELEMENT
+                    unsigned u = __builtin_bit_cast(unsigned, f);    //  reads element 0 on this compiler)
+                    u = (u + ((1u << (drop - 1)) - 1u) + ((u >> drop) & 1u)) & ~((1u << drop) - 1u);
+                    v[c] = __builtin_bit_cast(float, u);
+                }
+            }
             *(f32x4*)(a + 32 * i * LDK) = v;
         }
 #pragma unroll

@@ -36,6 +36,16 @@
 
 namespace fusg {
 
+// MODE 1 (FUSG_PREC_BF16, BASELINE configs[4]'s "bf16 MFMA conv path"): the same kernel with ONE bf16 product per
+// (a, w) pair instead of three fp16 products: operands rounded to bf16 (v_cvt_pk_bf16_f32, ties to even) while the
+// halo is staged, one LDS image instead of two, weights pre-rounded to bf16 in fragment order, v_mfma_f32_16x16x32_bf16
+// with fp32 accumulation.  bf16 has fp32's exponent range: no scaling, no range guard.  A third of the matrix work and
+// half the operand traffic; ~2^-9 relative error per operand - measured on the networks' fixtures: SSIM >= 0.9997 on
+// every image output, NOT bit-exact on the hourglass's keypoint argmax, which therefore stays on f16x3
+// (tests::test_reduced_precision_evidence, profiles/r02_parity.json).
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
 constexpr int HALO_CH = 32;          // channels per staged chunk = k per MFMA
 constexpr int HALO_PP = 32;          // halo pixel pitch in halves (64 B, slots swizzled - see above)
 
@@ -46,7 +56,8 @@ struct HaloK {
     int RP;                     // LDS pitch of a halo row in halves (halo_row_pitch)
     int tiles_x, tiles_per_img;
     int c1k;                    // K-channels of src1 (0 if absent)
-    const _Float16* wfrag;      // [tap][chunk][cout_pad/32][2 (k half)][2 (hi, lo)][64 lanes][8] halves
+    const _Float16* wfrag;      // f16x3: [tap][chunk][cout_pad/32][16-column half][hi|lo][64 lanes][8] halves
+                                // bf16:  [tap][chunk][cout_pad/32][16-column half][64 lanes][8] bf16
     const int* tile_list;       // optional: patch indices (within an image) to compute; MT = B * tile_count
     int tile_count;
     // Stride-2 k3/k4 pad-1 layers as four stride-1 convolutions of the parity sub-images x[2Y+i, 2X+j] (q = 2i+j):
@@ -77,8 +88,9 @@ constexpr int halo_waves(int tm, int tn) { return tm * tn == 1 ? 4 : (tm * tn ==
 constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
 #endif
 
-template <int TM, int TN, int WM, int WN, int PK, int NI>
+template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE>
 __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
+    constexpr bool BF = MODE == 1;
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
     constexpr int LOGC = 3;
@@ -152,8 +164,9 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const long img_pix0 = (long)b * p.H * p.W;
 
     // this wave's weight fragments: tiles (nt*BN/32 + wn*TN + j), j < TN
-    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 4 * 64 + lane) * 8;
-    const long wstep = (long)hk.nt32 * 4 * 64 * 8;            // halves per (tap, chunk) slab
+    constexpr int FPT = BF ? 2 : 4;                            // fragments (1 KiB) per 32-column tile: [ct] or [ct][hi|lo]
+    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * FPT * 64 + lane) * 8;
+    const long wstep = (long)hk.nt32 * FPT * 64 * 8;          // 16-bit elements per (tap, chunk) slab
     const float vfloor = (PK != PK_ELU && p.pre_relu) ? 0.f : -__builtin_inff();
     float amax = 0.f;
     const int nchq = p.C0 / CH;                                 // chunks per quadrant (quadrant form)
@@ -196,15 +209,22 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
-            h4 hi, lo;
-            split4(v, vfloor, hi, lo, amax);
-            if ((hexist >> j) & 1u) {
-                *(h4*)(Ah + hoff[j]) = hi;
-                *(h4*)(Al + hoff[j]) = lo;
+            if constexpr (BF) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], vfloor);
+                const bf4 hb = __builtin_convertvector(v, bf4);
+                if ((hexist >> j) & 1u) *(bf4*)(Ah + hoff[j]) = hb;
+            } else {
+                h4 hi, lo;
+                split4(v, vfloor, hi, lo, amax);
+                if ((hexist >> j) & 1u) {
+                    *(h4*)(Ah + hoff[j]) = hi;
+                    *(h4*)(Al + hoff[j]) = lo;
+                }
             }
         }
     };
-    struct BFrag { h8 f[TN][2][2]; };                 // [32-column tile][16-column half][hi, lo]
+    struct BFrag { h8 f[TN][2][BF ? 1 : 2]; };        // [32-column tile][16-column half][hi, lo] (bf16: one fragment)
     BFrag bfA, bfB;
     auto b_load = [&](BFrag& F, int cg, int tap) {
         int ch32 = cg;                                              // 32-channel chunk within its tap's K range
@@ -215,8 +235,8 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl)
-                    F.f[j][ct][hl] = *(const h8*)(base + ((j * 2 + ct) * 2 + hl) * 512);
+                for (int hl = 0; hl < (BF ? 1 : 2); ++hl)
+                    F.f[j][ct][hl] = *(const h8*)(base + ((j * 2 + ct) * (BF ? 1 : 2) + hl) * 512);
     };
 
     f32x4 acc[2 * TM][2 * TN];                        // [patch row of the wave][16-column group]
@@ -235,29 +255,43 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         else { const int ky = tap / hk.kw, kx = tap - ky * hk.kw; dyp = ky * hk.dil; dxp = kx * hk.dil; }
         const int hx = (lane & 15) + dxp;
         const int toff = dyp * hk.RP + hx * HPITCH + (((lane >> 4) ^ (((hx >> 2) & 1) << 1)) << 3);
-        h8 ah[2 * TM], al[2 * TM], bs[TN][2];
+        if constexpr (BF) {
+            bf8 ab[2 * TM];
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) {
-            ah[i] = *(const h8*)(Ah + abase[i] + toff);
-            al[i] = *(const h8*)(Al + abase[i] + toff);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) bs[j][ct] = scale_m11(F.f[j][ct][0]);   // wh * 2^-11: B operand of the al' term
-        // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one accumulator
-        // stalls the issue)
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
+            for (int i = 0; i < 2 * TM; ++i) ab[i] = *(const bf8*)(Ah + abase[i] + toff);
 #pragma unroll
             for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            term == 2 ? al[i] : ah[i], term == 0 ? F.f[j][ct][0] : term == 1 ? F.f[j][ct][1] : bs[j][ct],
-                            acc[i][2 * j + ct], 0, 0, 0);
+                        acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[i], __builtin_bit_cast(bf8, F.f[j][ct][0]),
+                                                                                       acc[i][2 * j + ct], 0, 0, 0);
+        } else {
+            h8 ah[2 * TM], al[2 * TM], bs[TN][2];
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                ah[i] = *(const h8*)(Ah + abase[i] + toff);
+                al[i] = *(const h8*)(Al + abase[i] + toff);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bs[j][ct] = scale_m11(F.f[j][ct][0]);   // wh * 2^-11: B operand of the al' term
+            // term-major order: consecutive MFMAs write different accumulators (a dependent chain on one accumulator
+            // stalls the issue)
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                term == 2 ? al[i] : ah[i], term == 0 ? F.f[j][ct][0] : term == 1 ? F.f[j][ct][1] : bs[j][ct],
+                                acc[i][2 * j + ct], 0, 0, 0);
+        }
     };
 
     // ---- prologue: halo of chunk 0 and the first weight fragments
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         if (cg >= nch) break;
     }
 
-    report_range(p, amax);
+    if constexpr (!BF) report_range(p, amax);
     // ---------------------------------------------------------------- epilogue
     auto pixfn = [&](int row, PixOff& po) {
         const int rr = wm * TM * 32 + row;
@@ -330,18 +364,22 @@ inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_
 inline bool halo_fits(int HH, int HW) { return HH * HW * 8 <= 2560 && halo_lds_bytes(HH, HW) <= 96 * 1024; }
 
 template <int TM, int TN, int WM, int WN>
-hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
+hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf16) {
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
     const int ni = (HP * 8 + 255) / 256;
     if (!halo_fits(k.HH, k.HW)) return hipErrorInvalidValue;
     const void* fn = nullptr;
-#define FUSG_PICK_NI(PKV)                                                                         \
-    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6>;                          \
-    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8>;                     \
-    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10>;
-    if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU) } else { FUSG_PICK_NI(PK_AFFINE) }
+#define FUSG_PICK_NI(PKV, MD)                                                                     \
+    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, MD>;                      \
+    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, MD>;                 \
+    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, MD>;
+    if (bf16) {
+        if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 1) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 1) } else { FUSG_PICK_NI(PK_AFFINE, 1) }
+    } else {
+        if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 0) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 0) } else { FUSG_PICK_NI(PK_AFFINE, 0) }
+    }
 #undef FUSG_PICK_NI
     if (hipError_t e = ensure_dyn_lds(fn, 96 * 1024); e != hipSuccess) return e;
     HaloK kk = k;
@@ -350,8 +388,8 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
 
-hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int);
-hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int);
-hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int);
+hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int, bool);
+hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int, bool);
+hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int, bool);
 
 }  // namespace fusg

@@ -104,7 +104,7 @@ class _Generator(FusedNet):
             b, sb = ops.conv_in(pb, a, pre_op=AR, pre=sa, pre_bstride=a.shape[1])
             y = ops.affine_act(b, sb[0], sb[1], L.ACT_NONE, res=y)
         def halo_ok(t):                                      # every phase launch qualifies for the halo kernel
-            return ops.PRECISION == "f16x3" and t.shape[1] % 32 == 0 and t.shape[2] % 8 == 0 and t.shape[3] % 16 == 0
+            return ops.halo_precision() and t.shape[1] % 32 == 0 and t.shape[2] % 8 == 0 and t.shape[3] % 16 == 0
         c, st = ops.conv_in(P["up1_ph"] if halo_ok(y) else P["up1"], y)
         c, st = ops.conv_in(P["up2_ph"] if halo_ok(c) else P["up2"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1])
         return ops.conv_rowsplit(P["head"], c, pre_op=AR, pre=st, pre_bstride=c.shape[1], act=self.final_act)

@@ -110,7 +110,7 @@ def entry_point(fn):
 
     def guarded(self, dev, args, kwargs):
         from . import ops
-        if ops.PRECISION != "f16x3" or ops._GUARD["depth"] > 0 or ops._GUARD["deferred"] > 0:
+        if not ops.range_guarded() or ops._GUARD["depth"] > 0 or ops._GUARD["deferred"] > 0:
             return fn(self, *args, **kwargs)
         snap = self._rng_snapshot()
         lists = [(a, list(a)) for a in args if isinstance(a, list)]

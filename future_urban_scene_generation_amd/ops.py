@@ -29,7 +29,21 @@ def _env_set(name: str) -> bool:
     return name in _os.environ
 
 
-_PREC = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
+_PREC = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3,
+         # BASELINE configs[4]: single-pass bf16 MFMA on the halo-kernel layers, f16x3 elsewhere (include/fusg.h)
+         "bf16": L.PREC_BF16,
+         # evidence paths (include/fusg.h): operands rounded to 8 / 16 significant bits on the exact-fp32 kernel
+         "emu_bf16": L.PREC_EMU_BF16, "emu_bf16x2": L.PREC_EMU_BF16X2}
+_EMU_BITS = {"emu_bf16": 8, "emu_bf16x2": 16}
+
+
+def _round_sig_bits(w: torch.Tensor, bits: int) -> torch.Tensor:
+    """fp32 -> nearest (ties to even) value with `bits` significant bits, as fp32."""
+    drop = 24 - bits
+    u = w.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    u = (u + ((1 << (drop - 1)) - 1) + ((u >> drop) & 1)) & ~((1 << drop) - 1) & 0xFFFFFFFF
+    u = torch.where(u >= (1 << 31), u - (1 << 32), u).to(torch.int32)
+    return u.view(torch.float32)
 PRECISION = _os.environ.get("FUSG_PRECISION", "f16x3")
 
 
@@ -67,6 +81,17 @@ class precision:
 # reaches the caller.
 _STATUS = {}
 _GUARD = {"depth": 0, "deferred": 0}
+
+
+def range_guarded() -> bool:
+    """Do launches of the current precision use the fp16 split (and hence its range status)?  f16x3 does everywhere;
+    bf16 does on the layers that do not run on the halo kernel (and the hourglass keeps f16x3 under it)."""
+    return PRECISION in ("f16x3", "bf16")
+
+
+def halo_precision() -> bool:
+    """Does the current precision route qualifying layers to the halo kernel?"""
+    return PRECISION in ("f16x3", "bf16")
 
 
 def status_word(device) -> torch.Tensor:
@@ -277,7 +302,14 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     d.res0 = desc(res0)
     d.res1 = desc(res1)
     dev = plan.dev
-    d.wpack = dev["wpack"].data_ptr()
+    prec_name = precision or PRECISION
+    if prec_name in _EMU_BITS:                # reduced-precision evidence path: weights rounded like the activations
+        key = "wpack_r%d" % _EMU_BITS[prec_name]
+        if key not in dev:
+            dev[key] = _round_sig_bits(dev["wpack"], _EMU_BITS[prec_name])
+        d.wpack = dev[key].data_ptr()
+    else:
+        d.wpack = dev["wpack"].data_ptr()
     d.bias = dev["bias"].data_ptr()
     d.ktab = dev["ktab"].data_ptr()
     if pre is not None:
@@ -314,6 +346,8 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
         if dev.get("wfrag") is not None:
             d.wfrag = dev["wfrag"].data_ptr()
             d.wfrag_order = dev["wfrag_order"]
+            if prec_name == "bf16" and dev.get("wfrag_bf16") is not None:
+                d.wfrag_bf16 = dev["wfrag_bf16"].data_ptr()
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None
@@ -379,7 +413,7 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     b, c, h, w = x.shape
     out = nhwc_empty(b, exact.cout, 2 * h, 2 * w, x.device)
     # split-K launches do not use the halo kernel: keep K whole where the phase launches qualify for it
-    halo = ((precision or PRECISION) == "f16x3" and c % 32 == 0 and h % 8 == 0 and w % 16 == 0
+    halo = ((precision or PRECISION) in ("f16x3", "bf16") and c % 32 == 0 and h % 8 == 0 and w % 16 == 0
             and _os.environ.get("FUSG_NO_HALO") is None)
     if isinstance(phases, ConvPlan):                               # all four phases in one launch, DepthToSpace store
         conv(phases, x, out=out, store=L.STORE_D2S, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,

@@ -65,6 +65,10 @@ class ConvPlan:
             if frag is None and self.tapunit_ok():
                 frag = frag_tapunit(wsplit, self)                      # few-channel k x k layer: per-k-step order
             self.dev["wfrag"] = None if frag is None else frag.to(device).contiguous()
+            fb = frag_bf16(self.wpack, self) if self.nphase == 1 else None
+            if fb is not None and self.s2d_ok():
+                fb = fb[s2d_tap_order(self.kh)].contiguous()
+            self.dev["wfrag_bf16"] = None if fb is None else fb.to(device).contiguous()
             self.dev["wfrag_order"] = 1 if self.s2d_ok() else (2 if self.tapunit_ok() else 0)   # fusg_conv_desc.wfrag_order
         return self
 
@@ -131,6 +135,21 @@ def frag_f16x3(wsplit: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]
     w = w.view(2, nt32, 2, 16, taps, nch, 4, 8)                 # hl, nt, ct, r, tap, chunk, g, j
     w = w.permute(4, 5, 1, 2, 0, 6, 3, 7)                       # tap, chunk, nt, ct, hl, g, r, j
     return w.reshape(taps, nch, nt32, 2, 2, 64, 8).contiguous()
+
+
+def frag_bf16(wpack: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:
+    """The weights rounded to bf16 (ties to even) in the halo kernel's fragment order for the single-pass bf16 mode
+    (fusg_conv_desc.wfrag_bf16): [tap][chunk32][cout_pad/32][16-column half][lane 64][8], lane = (k >> 3) * 16 + column.
+    None when the layer cannot use the halo kernel."""
+    taps = plan.kh * plan.kw
+    ctot = plan.c0k + plan.c1k
+    if plan.nphase != 1 or taps < 1 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
+        return None
+    w = wpack[0].to(torch.bfloat16)                             # [cout_pad, k_pad]
+    nt32, nch = plan.cout_pad // 32, ctot // 32
+    w = w.view(nt32, 2, 16, taps, nch, 4, 8)                    # nt, ct, r, tap, chunk, g, j
+    w = w.permute(3, 4, 0, 1, 5, 2, 6)                          # tap, chunk, nt, ct, g, r, j
+    return w.reshape(taps, nch, nt32, 2, 64, 8).contiguous()
 
 
 def s2d_quadrant_taps(k: int):

@@ -158,7 +158,7 @@ class VehiclePipeline:
     # says whether any pass since the last call was affected - call it before consuming outputs.
     def _guarded(self, fn, args, check: str, rng_state):
         from . import ops
-        if ops.PRECISION != "f16x3" or check is None:
+        if not ops.range_guarded() or check is None:
             return fn(*args)
         with ops.defer_range_check():
             out = fn(*args)
@@ -179,7 +179,7 @@ class VehiclePipeline:
         (`ops.precision("f32")`)."""
         from . import ops
         torch.cuda.synchronize(self.device)
-        if ops.PRECISION != "f16x3":
+        if not ops.range_guarded():
             return False
         with torch.cuda.device(self.device):
             return ops.range_exceeded(self.device)
@@ -341,9 +341,9 @@ class CompiledPass:
                 raise RuntimeError("CompiledPass.run: the current stream differs from the one the pass was recorded on")
             if ops.PRECISION != self.precision:
                 raise RuntimeError(f"CompiledPass.run: recorded with precision {self.precision}, now {ops.PRECISION}")
-            rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync" and ops.PRECISION == "f16x3") else None
+            rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync" and ops.range_guarded()) else None
             out = self._issue(batch, vehicle_seeds)
-            if ops.PRECISION != "f16x3" or check != "sync":
+            if not ops.range_guarded() or check != "sync":
                 return out
             if not ops.range_exceeded(self.device):
                 return out

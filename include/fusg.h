@@ -79,14 +79,24 @@ typedef enum fusg_store_mode {
 
 /* Arithmetic of the conv contraction.
  * F32:   v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (157 TFLOP/s dense peak).
- * F16X3: operands split into fp16 pairs, a*w ~= ah*wh + ah*wl + al'*(wh*2^-11) on v_mfma_f32_32x32x16_f16 with
- *        fp32 accumulation; al' = (a - ah)*2^11 and the weights carry a per-output-channel power-of-two scale
+ * F16X3: operands split into fp16 pairs, a*w ~= ah*wh + ah*wl + al'*(wh*2^-11) on v_mfma_f32_16x16x32_f16 (halo kernel; 32x32x16 in
+ *        the generic kernels) with fp32 accumulation; al' = (a - ah)*2^11 and the weights carry a per-output-channel power-of-two scale
  *        (wscale), so every operand in fp16's normal range [2^-14, 2^15) keeps >= 22 significant bits: the
  *        error against fp64 is at or below that of an fp32 fmaf chain for operand scales 1e-4 .. 1e4
  *        (tools/emu_split.py, tests/test_gpu_ops.py::test_f16x3_scale_sweep).  3 MFMA passes at the fp16 rate.
  *        Nothing is clamped: a launch that stages an operand with |x| >= 2^15 (or a non-finite one) sets
- *        *status = 1 and its output is unspecified; the caller must then redo the work with F32. */
-typedef enum fusg_precision { FUSG_PREC_F32 = 0, FUSG_PREC_F16X3 = 1 } fusg_precision;
+ *        *status = 1 and its output is unspecified; the caller must then redo the work with F32.
+ * EMU_BF16 / EMU_BF16X2: evidence paths, not production: the F32 kernel with every staged activation rounded to 8 / 16
+ *        significant bits (the caller passes weights rounded the same way in `wpack`): products of such operands are
+ *        exact in fp32, so this is the arithmetic of a single-pass bf16 (resp. two-piece bf16) MFMA contraction with
+ *        fp32 accumulation, at fp32-MFMA speed.  Used to decide BASELINE configs[4] with data.
+ * BF16:  BASELINE configs[4]'s "bf16 MFMA conv path": launches that qualify for the halo kernel (the layers that carry the
+ *        FLOPs) contract in ONE bf16 product per operand pair on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 as
+ *        they are staged, weights from `wfrag_bf16`, fp32 accumulation); every other launch runs as F16X3, whose
+ *        fields must be given too.  Measured: SSIM >= 0.9997 on every image output of the path, keypoint argmax NOT
+ *        bit-exact - the hourglass module keeps F16X3 under this setting. */
+typedef enum fusg_precision { FUSG_PREC_F32 = 0, FUSG_PREC_F16X3 = 1, FUSG_PREC_EMU_BF16 = 2, FUSG_PREC_EMU_BF16X2 = 3,
+                              FUSG_PREC_BF16 = 4 } fusg_precision;
 
 typedef enum fusg_tile {       /* workgroup tile (output pixels x output channels); 0 = auto */
     FUSG_TILE_AUTO = 0, FUSG_TILE_128x128 = 1, FUSG_TILE_128x64 = 2, FUSG_TILE_128x32 = 3,
@@ -182,6 +192,10 @@ typedef struct fusg_conv_desc {
      * outside the split's range - see fusg_precision.  Sticky: the library never clears it. */
     const float*   wscale;
     int32_t*       status;
+    /* FUSG_PREC_BF16 only: the weights rounded to bf16 (ties to even) in the halo kernel's fragment order
+     * [tap][chunk32][cout_pad/32][16-column half][64 lanes][8 bf16], same tap order as `wfrag` (pack.py: frag_bf16).
+     * NULL: the launch runs as F16X3. */
+    const void*    wfrag_bf16;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
@@ -341,9 +355,9 @@ int         fusg_version(void);
 const char* fusg_last_error(void);
 /* Kernel family of this thread's last fusg_conv2d launch (tests assert that the intended path ran):
  * 0 generic fp32, 1 generic split-fp16, 2 halo, 3 halo in parity-quadrant form (stride 2), 4 tap-unit kernel
- * (few-channel stems); -1 none yet. */
+ * (few-channel stems), 5 halo kernel in single-pass bf16; -1 none yet. */
 enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3,
-       FUSG_CONV_TAPUNIT = 4 };
+       FUSG_CONV_TAPUNIT = 4, FUSG_CONV_HALO_BF16 = 5 };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their

@@ -475,3 +475,62 @@ def test_f16x3_out_of_range_raises_status(name, cin, cout, k, pad, H, W, pre, fa
     assert not ops.range_exceeded(dev())
     ref = F.conv2d({L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre].double(), w.double(), None, padding=pad)
     assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def test_reduced_precision_emulation_is_what_it_says(precision):
+    """FUSG_PREC_EMU_BF16 / EMU_BF16X2 (the evidence paths of test_reduced_precision_evidence): the launch must equal a
+    convolution of operands rounded to 8 / 16 significant bits with exact products - checked against fp64 on operands
+    rounded on the CPU - and differ from the unrounded convolution by about 2^-9 / 2^-17 per operand."""
+    if precision != "f32":
+        pytest.skip("one run")
+    x = _rand(2, 64, 16, 16, seed=21)
+    w = _rand(32, 64, 3, 3, seed=22, scale=0.05)
+    plan = pack.pack_conv(w, None, pad=1)
+    exact = F.conv2d(x.double(), w.double(), padding=1)
+    den = F.conv2d(x.double().abs(), w.double().abs(), padding=1)
+    for name, bits in (("emu_bf16", 8), ("emu_bf16x2", 16)):
+        xr, wr = ops._round_sig_bits(x, bits).double(), ops._round_sig_bits(w, bits).double()
+        if bits == 8:
+            assert torch.equal(xr.float(), x.bfloat16().float())          # 8 significant bits, ties to even = bf16
+        ref = F.conv2d(xr, wr, padding=1)
+        got = ops.conv(plan, _nhwc(x), precision=name).cpu().double()
+        assert float(((got - ref).abs() / den).max()) < 2e-6             # only the fp32 accumulation differs
+        err = float(((got - exact).abs() / den).max())
+        assert 2.0 ** -(bits + 5) < err < 2.0 ** -(bits - 1), (name, err)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,pm,H,W,pre", [
+    (128, 128, 3, 1, 1, 1, 0, 32, 32, L.PRE_ELU),          # VUnet residual shape
+    (256, 256, 3, 1, 2, 2, 1, 16, 16, L.PRE_AFFINE_RELU),  # EdgeConnect dilated, reflect
+    (64, 32, 3, 1, 1, 1, 0, 32, 64, L.PRE_NONE),           # BN = 32 tile
+    (128, 64, 5, 1, 2, 1, 1, 16, 32, L.PRE_NONE),          # 5x5 (NI = 8)
+    (64, 128, 4, 2, 1, 1, 1, 32, 64, L.PRE_RELU),          # stride 2 in parity-quadrant form
+    (128, 256, 1, 1, 0, 1, 0, 16, 16, L.PRE_NONE),         # 1x1
+])
+def test_bf16_halo_conv(cin, cout, k, stride, pad, dil, pm, H, W, pre, precision):
+    """FUSG_PREC_BF16: the halo kernel in single-pass bf16 equals a convolution of bf16-rounded operands with exact
+    products (only the fp32 accumulation order differs), on every pre-op / padding / stride form it supports."""
+    if precision != "f16x3":
+        pytest.skip("one run")
+    x = _rand(2, cin, H, W, seed=31)
+    w = _rand(cout, cin, k, k, seed=32, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=33)
+    sc, sh = _rand(cin, seed=34).abs() + 0.5, _rand(cin, seed=35) * 0.1
+    plan = pack.pack_conv(w, b, stride=stride, pad=pad, dil=dil, pad_mode=pm)
+    xp = {L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x),
+          L.PRE_AFFINE_RELU: F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))}[pre]
+    xr, wr = xp.bfloat16().double(), w.bfloat16().double()
+    xin = F.pad(xr, (pad,) * 4, mode="reflect") if pm else xr
+    ref = F.conv2d(xin, wr, b.double(), stride=stride, padding=0 if pm else pad, dilation=dil)
+    den = F.conv2d(xin.abs(), wr.abs(), None, stride=stride, padding=0 if pm else pad, dilation=dil) + 1e-30
+    kw = dict(pre=(sc.to(dev()), sh.to(dev()))) if pre == L.PRE_AFFINE_RELU else {}
+    got = ops.conv(plan, _nhwc(x), pre_op=pre, precision="bf16", ksplit=1, **kw)
+    assert ops.last_conv_kernel() == 5, ops.last_conv_kernel()
+    assert float(((got.cpu().double() - ref).abs() / den).max()) < (3e-5 if pre == L.PRE_ELU else 3e-6)   # (GPU exp in the ELU)
+    # a layer that does not qualify for the halo kernel runs as f16x3 under the same setting
+    w2 = _rand(16, 12, 3, 3, seed=36, scale=0.1)
+    p2 = pack.pack_conv(w2, None, pad=1)
+    x2 = _rand(1, 12, 9, 9, seed=37)
+    g2 = ops.conv(p2, _nhwc(x2), precision="bf16")
+    assert ops.last_conv_kernel() in (1, 4)
+    _close(g2, F.conv2d(x2, w2, padding=1), rtol=1e-5, atol=1e-5)

@@ -17,6 +17,11 @@ import os
 import sys
 
 
+CONV_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "conv_splitk_reduce")     # every dispatch a fusg_conv2d call makes
+# one fusg_conv2d call = one launch, except split-K launches, which add their reduce dispatch: calls = main dispatches
+MAIN_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit")
+
+
 def load(d, counter):
     f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
     tot = collections.defaultdict(float)
@@ -24,9 +29,12 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        k = "conv" if ("conv_igemm" in r["Kernel_Name"] or "conv_halo" in r["Kernel_Name"]) else "other"
+        name = r["Kernel_Name"]
+        k = "conv" if any(t in name for t in CONV_KERNELS) else "other"
         tot[k] += float(r["Counter_Value"])
         n[k].add(r["Dispatch_Id"])
+        if any(t in name for t in MAIN_KERNELS):
+            n["conv_calls"].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in n.items()}
 
 
@@ -36,10 +44,15 @@ def main():
     wt, wn = load(wd, "WRITE_SIZE")
     fetch_b = ft["conv"] * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
     write_b = wt["conv"] * 1024
-    launches = fn["conv"]
-    out = {"conv_launches": launches, "conv_fetch_bytes_total": fetch_b, "conv_write_bytes_total": write_b,
+    launches = fn["conv_calls"]
+    import datetime
+    out = {"conv_launches": launches, "conv_dispatches": fn["conv"], "conv_fetch_bytes_total": fetch_b, "conv_write_bytes_total": write_b,
            "conv_bytes_per_launch": (fetch_b + write_b) / max(1, launches),
+           "definition": "HBM bytes of every dispatch a fusg_conv2d call makes (generic / halo / tap-unit kernels + split-K "
+                         "reduce), per fusg_conv2d call - the same unit as bench.py's roofline.achieved",
            "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide streaming reads), WRITE_SIZE KiB x1024",
+           "collected": datetime.date.today().isoformat() + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of "
+                        "bench.py --precision f16x3 (serialised branches)",
            "source": [fd, wd]}
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(repo, "profiles", "hbm_traffic_latest.json"), "w") as f:
