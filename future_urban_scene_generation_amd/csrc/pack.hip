@@ -33,7 +33,7 @@ static bool geom(const fusg_pack_spec& s, PackGeom& g) {
     g.s2d_ok = s.stride == 2 && s.kh == s.kw && (s.kh == 3 || s.kh == 4) && s.pad == 1 && s.dil == 1 && s.upsample == 0 &&
                g.c1k == 0 && g.c0k % 32 == 0 && g.c0k > 0;
     g.unit = g.c0k % 8 == 0 ? 8 : 4;
-    g.tap_ok = g.taps >= 9 && g.c1k == 0 && g.c0k >= 4 && g.c0k <= 24 && s.dil == 1 && s.upsample == 0 &&
+    g.tap_ok = (g.taps >= 9 || g.c0k <= 8) && g.c1k == 0 && g.c0k >= 4 && g.c0k <= 24 && s.dil == 1 && s.upsample == 0 &&
                g.k_pad >= g.taps * g.c0k && g.taps * (g.c0k / g.unit) <= 160;
     g.nsteps = (g.taps * g.c0k + 15) / 16;
     return true;

@@ -88,7 +88,7 @@ class ConvPlan:
         import os
         taps = self.kh * self.kw
         unit = 8 if self.c0k % 8 == 0 else 4
-        return (not os.environ.get("FUSG_NO_TAPUNIT") and self.nphase == 1 and taps >= 9 and self.c1k == 0
+        return (not os.environ.get("FUSG_NO_TAPUNIT") and self.nphase == 1 and (taps >= 9 or self.c0k <= 8) and self.c1k == 0
                 and 4 <= self.c0k <= 24 and self.dil == 1 and self.upsample == 0 and self.stride in (1, 2)
                 and self.k_pad >= taps * self.c0k and taps * (self.c0k // unit) <= 160 and self.rowsplit is None)
 

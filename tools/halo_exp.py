@@ -116,6 +116,9 @@ def main():
         ("hg 128->256 1x1 @64 affine", 32, 128, 256, 1, 0, 64, L.PRE_AFFINE_RELU, 0, 1),
         ("hg 128->128 3x3 @32 affine", 32, 128, 128, 3, 1, 32, L.PRE_AFFINE_RELU, 0, 1),
         ("hg 128->128 3x3 @16 affine", 32, 128, 128, 3, 1, 16, L.PRE_AFFINE_RELU, 0, 1),
+        ("vu 6->128 1x1 @256 elu", 32, 6, 128, 1, 0, 256, L.PRE_ELU, 0, 1),
+        ("vu 3->32 1x1 @256 elu", 32, 3, 32, 1, 0, 256, L.PRE_ELU, 0, 1),
+        ("hg 12->256 1x1 @64", 32, 12, 256, 1, 0, 64, L.PRE_NONE, 0, 1),
     ]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = args[0] if args else None
@@ -132,8 +135,10 @@ def main():
             pre = (torch.rand(cin, generator=g).to(dev) + 0.5, torch.randn(cin, generator=g).to(dev) * 0.1)
         Ho = H * (2 if up else 1)
         fl = 2.0 * B * Ho * Ho * cout * cin * k * k
-        ms, mhz, wat = timer(lambda: ops.conv(plan, x, pre_op=pre_op, pre=pre, precision="f16x3"))
-        print(f"{tag:22s} {name:30s} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF {mhz:5.0f} MHz {wat:5.0f} W {ms * wat / 1e3:.3f} J", flush=True)
+        prec = os.environ.get("FUSG_EXP_PRECISION", "f16x3")
+        ms, mhz, wat = timer(lambda: ops.conv(plan, x, pre_op=pre_op, pre=pre, precision=prec))
+        tagk = tag + ":" + prec + ":k" + str(ops.last_conv_kernel())
+        print(f"{tagk:26s} {name:30s} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF {mhz:5.0f} MHz {wat:5.0f} W {ms * wat / 1e3:.3f} J", flush=True)
 
 
 if __name__ == "__main__":
