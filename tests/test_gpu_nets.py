@@ -37,8 +37,11 @@ from future_urban_scene_generation_amd.vunet.models import Vunet_fix_res   # noq
 from future_urban_scene_generation_amd.warp_learn.models import G_Resnet   # noqa: E402
 
 DEV = "cuda:0"
-TOL = 2e-4            # raw network outputs, relative to the tensor's largest magnitude (observed: profiles/r02_parity.json)
-TOL_ILL = 2e-3        # ICN on the deliberately ill-conditioned fixtures (InstanceNorm of near-constant planes)
+# Bars on raw network outputs, relative to the tensor's largest magnitude = ~10x the worst value observed on the MI355X
+# in round 2, for either precision (profiles/r02_parity.json): hourglass 1.0e-6, VUnet 1.7e-6, EdgeConnect 1.3e-5, ICN
+# 2.3e-5 (its fixtures are ill-conditioned on purpose: InstanceNorm of near-constant planes amplifies every rounding).
+TOL_HG, TOL_VU, TOL_EC, TOL_ICN = 1e-5, 2e-5, 1.5e-4, 2.5e-4
+TOL = TOL_ICN
 
 
 def _rel(got, ref, what="rel_err"):
@@ -93,8 +96,8 @@ def test_hourglass(tag, B, R):
     hm = out["heatmaps"]
     assert hm[1].is_contiguous() and tuple(hm[1].shape) == (B, 12, R // 4, R // 4)
     ref = oracle.hourglass_forward(synth_sd("hg"), x)["heatmaps"]
-    assert _rel(hm[0], ref[0]) < TOL and _rel(hm[1], ref[1]) < TOL
-    assert _rel(hm[1], g["hm1"]) < TOL
+    assert _rel(hm[0], ref[0]) < TOL_HG and _rel(hm[1], ref[1]) < TOL_HG
+    assert _rel(hm[1], g["hm1"]) < TOL_HG
     # integer contract: bit-exact argmax / get_maxima vs the reference's golden values
     idx = ops.argmax_hw(hm[1]).cpu().numpy().astype(np.int64)
     assert np.array_equal(idx, g["argmax"])
@@ -111,8 +114,8 @@ def test_icn(tag, B, R):
     out = model("icn")(x.to(DEV))
     assert out.is_contiguous() and tuple(out.shape) == (B, 3, R, R)
     ref = oracle.icn_forward(synth_sd("icn"), x)
-    assert _rel(out, ref) < TOL
-    assert _rel(out, g["out"]) < TOL
+    assert _rel(out, ref) < TOL_ICN
+    assert _rel(out, g["out"]) < TOL_ICN
     d, ss = _u8(ops.to_image_u8(out).cpu().numpy(), g["img_u8"])
     assert d <= 1 and ss >= 0.999
 
@@ -130,7 +133,7 @@ def test_vunet_traj_sequence(tag, B, R, manifest):
     sums = np.array([float(t.cpu().double().sum()) for t in ds])
     np.testing.assert_allclose(sums, g["skip_sums"], rtol=2e-3, atol=float(np.max(g["skip_abs"])) * 1e-5)
     for k in (0, 5, 13):
-        assert _rel(ds[k][:, :, :8, :8], g[f"skip{k}_corner"]) < TOL
+        assert _rel(ds[k][:, :, :8, :8], g[f"skip{k}_corner"]) < TOL_VU
     xt, mu_s, z_s = vu.forward_dec_down(do, ds, mu_app)
     assert ds == []
     assert xt.is_contiguous()
@@ -138,14 +141,14 @@ def test_vunet_traj_sequence(tag, B, R, manifest):
                     ("mu_app0", mu_app[0]), ("mu_app1", mu_app[1]), ("z_app0", z_app[0]), ("z_app1", z_app[1]),
                     ("dec_out", do[0]), ("x_tilde", xt), ("mu_s0", mu_s[0]), ("mu_s1", mu_s[1]),
                     ("z_s0", z_s[0]), ("z_s1", z_s[1])]:
-        assert _rel(t, g[name]) < TOL, name
+        assert _rel(t, g[name]) < TOL_VU, name
     d, ss = _u8(ops.to_image_u8(xt).cpu().numpy(), g["img_u8"])
     assert d <= 1 and ss >= 0.999
     # later frame (appearance code reused)
     y2 = synth_inputs("vunet", B, R, 1)["y_tilde"]
     torch.manual_seed(manifest["cases"][tag]["later_seed"])
     do2, ds2 = vu.forward_dec_up(y2.to(DEV))
-    assert _rel(vu.forward_dec_down(do2, ds2, mu_app)[0], g["x_tilde_later"]) < TOL
+    assert _rel(vu.forward_dec_down(do2, ds2, mu_app)[0], g["x_tilde_later"]) < TOL_VU
 
 
 def test_vunet_forward_entry_and_nchw_inputs(manifest):
@@ -154,7 +157,7 @@ def test_vunet_forward_entry_and_nchw_inputs(manifest):
     i = synth_inputs("vunet", 1, 256)
     torch.manual_seed(manifest["cases"]["vunet_b1_r256"]["fwd_seed"])
     xt, mu_app, mu_shape = vu(i["y_tilde"].to(DEV), i["x"].to(DEV))
-    assert _rel(xt, g["fwd_x_tilde"]) < TOL and _rel(mu_shape[0], g["fwd_mu_shape0"]) < TOL
+    assert _rel(xt, g["fwd_x_tilde"]) < TOL_VU and _rel(mu_shape[0], g["fwd_mu_shape0"]) < TOL_VU
     # callers may hand back plain NCHW copies of the intermediate tensors
     torch.manual_seed(5)
     do, ds = vu.forward_dec_up(i["y_tilde"].to(DEV))
@@ -175,15 +178,15 @@ def test_edgeconnect(tag, B, R):
     em, im = em.to(DEV).eval(), im.to(DEV).eval()
     gray, edge, mask, img = (i[k].to(DEV) for k in ("gray", "edge", "mask", "img"))
     e = em(gray, edge, mask).detach()
-    assert _rel(e, g["edge_out"]) < TOL
+    assert _rel(e, g["edge_out"]) < TOL_EC
     p = im(img, e, mask)
-    assert _rel(p, g["inpaint_out"]) < TOL
+    assert _rel(p, g["inpaint_out"]) < TOL_EC
     d, ss = _u8(ops.merge_u8(p, img, mask).cpu().numpy(), g["merged_u8"])
     assert d <= 1 and ss >= 0.999
     # bare generators behave like the wrappers' generator
     m = i["mask"]
     e2 = model("edge")(torch.cat((i["gray"] * (1 - m) + m, i["edge"] * (1 - m), m), 1).to(DEV))
-    assert _rel(e2, g["edge_out"]) < TOL
+    assert _rel(e2, g["edge_out"]) < TOL_EC
 
 
 def test_modules_refuse_cpu_and_training():
@@ -216,7 +219,7 @@ def test_high_res_512(precision):
     x = synth_inputs("icn", 1, 512)["x"]
     out = model("icn")(x.to(DEV))
     ref = oracle.icn_forward(synth_sd("icn"), x)
-    assert tuple(out.shape) == (1, 3, 512, 512) and _rel(out, ref) < TOL
+    assert tuple(out.shape) == (1, 3, 512, 512) and _rel(out, ref) < TOL_ICN
     assert oracle.ssim(ops.to_image_u8(out).cpu().numpy(), oracle.to_image_u8(ref)) >= 0.999
     hx = synth_inputs("hg", 1, 512)["x"]
     hm = model("hg")(hx.to(DEV))["heatmaps"][-1]
@@ -331,7 +334,7 @@ def test_hourglass_non_square(precision):
     x = synth_inputs("hg", 1, 256)["x"][:, :, :128, :192].contiguous()
     hm = model("hg")(x.to(DEV))["heatmaps"][-1]
     ref = oracle.hourglass_forward(synth_sd("hg"), x)["heatmaps"][-1]
-    assert tuple(hm.shape) == (1, 12, 32, 48) and _rel(hm, ref) < TOL
+    assert tuple(hm.shape) == (1, 12, 32, 48) and _rel(hm, ref) < TOL_HG
     assert np.array_equal(ops.argmax_hw(hm).cpu().numpy(), oracle.heatmap_argmax(ref))
 
 
@@ -489,7 +492,7 @@ def test_vunet_and_edgeconnect_at_512(precision):
     rmu, _ = oracle.vunet_enc_down(sd, reo, res_)
     rdo, rds = oracle.vunet_dec_up(sd, i["y_tilde"])
     ref = oracle.vunet_dec_down(sd, rdo, rds, rmu)[0]
-    assert tuple(xt.shape) == (1, 3, R, R) and _rel(xt, ref) < TOL
+    assert tuple(xt.shape) == (1, 3, R, R) and _rel(xt, ref) < TOL_VU
     d, ss = _u8(ops.to_image_u8(xt).cpu().numpy(), oracle.to_image_u8(ref))
     assert d <= 1 and ss >= 0.999
     e = synth_inputs("edge", 1, R)
@@ -499,10 +502,10 @@ def test_vunet_and_edgeconnect_at_512(precision):
     em, im = em.to(DEV).eval(), im.to(DEV).eval()
     ge = em(e["gray"].to(DEV), e["edge"].to(DEV), e["mask"].to(DEV))
     re_ = oracle.edge_model_forward(synth_sd("edge"), e["gray"], e["edge"], e["mask"])
-    assert _rel(ge, re_, "rel_err_edge") < TOL
+    assert _rel(ge, re_, "rel_err_edge") < TOL_EC
     gp = im(e["img"].to(DEV), ge, e["mask"].to(DEV))
     rp = oracle.inpaint_model_forward(synth_sd("inpaint"), e["img"], re_, e["mask"])
-    assert _rel(gp, rp, "rel_err_inpaint") < TOL
+    assert _rel(gp, rp, "rel_err_inpaint") < TOL_EC
 
 
 def test_reduced_precision_evidence(precision):
@@ -585,7 +588,7 @@ def test_bf16_path_meets_the_image_bar_and_keeps_keypoints_exact(precision):
         gh = load_golden("hg_b1_r256")
         hm = model("hg")(synth_inputs("hg", 1, 256)["x"].to(DEV))["heatmaps"][-1]
         assert np.array_equal(ops.argmax_hw(hm).cpu().numpy().astype(np.int64), gh["argmax"])
-        assert _rel(hm, gh["hm1"], "hg_rel_err") < TOL                                    # (f16x3 inside)
+        assert _rel(hm, gh["hm1"], "hg_rel_err") < TOL_HG                                    # (f16x3 inside)
         gv = load_golden("vunet_b1_r256")
         vu, i = model("vunet"), synth_inputs("vunet", 1, 256)
         torch.manual_seed(manifest_seed("vunet_b1_r256"))
