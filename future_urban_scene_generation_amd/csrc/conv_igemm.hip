@@ -182,6 +182,9 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     const TileCfg tc = kTiles[d->tile];
     FUSG_CHECK(d->cout_pad % tc.bn == 0, "conv2d: cout_pad %d not a multiple of tile N %d", d->cout_pad, tc.bn);
     if (d->ksplit > 1) FUSG_CHECK(d->workspace && (((uintptr_t)d->workspace) & 15) == 0, "conv2d: split-K needs a 16B-aligned workspace");
+    if (d->ksplit > 1 && d->splitk_counters)
+        FUSG_CHECK((long)((Ml + tc.bm - 1) / tc.bm) * (d->cout_pad / tc.bn) * nphase <= d->splitk_counters_len,
+                   "conv2d: %d split-K counters for %ld tiles", d->splitk_counters_len, (long)((Ml + tc.bm - 1) / tc.bm) * (d->cout_pad / tc.bn) * nphase);
 
     ConvK k;
     memset(&k, 0, sizeof(k));
@@ -192,6 +195,7 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     if (d->res0.data) { k.res0 = (const float*)d->res0.data; k.r0n = d->res0.sn; k.r0c = d->res0.sc; k.r0h = d->res0.sh; k.r0w = d->res0.sw; }
     if (d->res1.data) { k.res1 = (const float*)d->res1.data; k.r1n = d->res1.sn; k.r1c = d->res1.sc; k.r1h = d->res1.sh; k.r1w = d->res1.sw; }
     k.ws = d->workspace;
+    k.counters = d->ksplit > 1 ? d->splitk_counters : nullptr;
     k.qy0 = d->q_oy; k.qx0 = d->q_ox;
     k.zeros = zero_line();
     if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
@@ -389,7 +393,7 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
         default:                e = launch_tile_64x128(k, grid, s, pk, gen); break;
     }
     if (e != hipSuccess) { set_error("conv2d launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
-    if (d->ksplit > 1) {
+    if (d->ksplit > 1 && k.counters == nullptr) {
         const long total = (long)nphase * k.M * (k.Cout_pad >> 2);
         hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, nphase);
         e = hipGetLastError();

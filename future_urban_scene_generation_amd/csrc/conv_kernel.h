@@ -56,6 +56,8 @@ struct ConvK {
                              // time (pack.split_f16x3); the epilogue computes acc * wscale[n] + bias[n].  NULL = 1.
     int* status;             // f16x3 path: set to 1 by any workgroup that stages an operand with |x| >= 2^15 (outside
                              // the range the fp16 split represents); the caller re-runs the pass in exact fp32
+    int* counters;           // split-K: one arrival counter per (phase, tile), zero between launches (the last arriver
+                             // resets it); NULL = the host launches conv_splitk_reduce instead
     int round_bits;          // exact-fp32 kernel only, 0 = off: round every staged activation to this many significant bits
                              // (8 = bf16, 16 = two bf16 pieces) - the numerics of a reduced-precision MFMA path emulated
                              // on the fp32 matrix cores (products of such operands are exact in fp32), for the bf16
@@ -222,6 +224,57 @@ __device__ __forceinline__ void epilogue_vec16(const ConvK& p, float* wlds, cons
             for (int r = 0; r < 4; ++r)
                 wlds[(i * 16 + (lane >> 4) * 4 + r) * PITCH + j * 16 + (lane & 15)] = acc[i][j][r];
     epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base);
+}
+
+// ---- in-launch split-K combine ---------------------------------------------------------------------------------
+// Small-M layers split K over gridDim.z workgroups that each write a partial slab.  Instead of a second launch that
+// sums the slabs (one more dependent kernel boundary per layer: ~8 us on a chain of 74 such layers per pass), the
+// workgroup that arrives LAST at the tile's counter sums them - in slab order, so the result does not depend on the
+// arrival order and is bit-identical to the separate reduce kernel's - and runs the epilogue.  Placement-independent
+// hand-off as cdna_hip_programming.md §5 ("Projection GEMM at M = 256", item 2) prescribes: plain slab stores ->
+// every wave s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent-scope release fence, vmcnt(0), relaxed agent-scope
+// ticket; the last arriver: agent-scope acquire fence, vmcnt(0), barrier, plain loads.  Slabs are tiny (<= 64 KiB per
+// tile and split), which is where the guide says the in-launch combine beats the extra boundary.
+__device__ __forceinline__ bool splitk_arrive(const ConvK& p, int tile_id) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == p.ksplit - 1;
+        if (last) {
+            __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_combine(const ConvK& p, int phase, int mt, int nt) {
+    constexpr int N4 = BN / 4;
+    for (int idx = threadIdx.x; idx < BM * N4; idx += 256) {
+        const int m = mt * BM + idx / N4, c4 = nt * N4 + idx % N4;
+        PixOff po;
+        if (!pix_offsets(p, phase, m, po)) continue;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.ksplit; ++k)
+            s += *(const f32x4*)(p.ws + ((long)(phase * p.ksplit + k) * p.M + m) * p.Cout_pad + c4 * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = c4 * 4 + c;
+            if (n < p.Cout) {
+                PixOff co;
+                chan_offsets(p, n, co);
+                epi_store(p, po, co, p.bias[n], p.wscale ? p.wscale[n] : 1.f, s[c]);
+            }
+        }
+    }
 }
 
 // TM x TN 32x32 tiles per wave, WM x WN waves; PK = pre-op kind; GEN = generic addressing
@@ -435,6 +488,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK p) {
                     for (int j = 0; j < TN; ++j) ws[(long)m * p.Cout_pad + ncol0 + j * 32] = acc[i][j][r];
                 }
             }
+        if (p.counters == nullptr) return;                                   // the host launches the reduce kernel
+        if (!splitk_arrive(p, phase * gridDim.x + tile)) return;
+        splitk_combine<BM, BN>(p, phase, mt, nt);
         return;
     }
     if (p.vec_epi) {

@@ -373,6 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                     for (int j = 0; j < TN; ++j) ws[(long)m * p.Cout_pad + ncol0 + j * 32] = acc[i][j][r];
                 }
             }
+        if (p.counters == nullptr) return;                                   // the host launches the reduce kernel
+        if (!splitk_arrive(p, phase * gridDim.x + tile)) return;
+        splitk_combine<BM, BN>(p, phase, mt, nt);
         return;
     }
     if (p.vec_epi) {

@@ -242,6 +242,20 @@ def to_nchw(t: torch.Tensor) -> torch.Tensor:
 _WS = {}
 
 
+_COUNTERS = {}
+N_COUNTERS = 4096
+
+
+def _splitk_counters(device) -> torch.Tensor:
+    """Zeroed arrival counters of the in-launch split-K combine (fusg_conv_desc.splitk_counters), one array per device
+    and stream: launches on one stream run in order and each leaves its counters zero."""
+    key = (str(device), stream_ptr())
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros(N_COUNTERS, device=device, dtype=torch.int32)
+    return c
+
+
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Stream-ordered split-K scratch, grown on demand (one per device and stream: branches of the crop pass
     run concurrently on their own streams)."""
@@ -354,6 +368,13 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     if nbytes > 0:
         ws = _workspace(x0.device, nbytes)
         d.workspace = ws.data_ptr()
+        # In-launch combine by the last-arriving workgroup (fusg_conv_desc.splitk_counters): correct and bit-identical,
+        # but measured SLOWER than the separate reduce kernel on this chip (B=1 replay 2.6 -> 3.3 ms/pass, B=32 conv time
+        # 26.4 -> 27.1 ms/step): every split workgroup pays an agent-scope release (an L2 write-back) that costs more
+        # than the kernel boundary it saves - as cdna_hip_programming.md §5.6 predicts for seams of this size.  Opt-in.
+        if _env_set("FUSG_SPLITK_IN_LAUNCH"):
+            d.splitk_counters = _splitk_counters(x0.device).data_ptr()
+            d.splitk_counters_len = N_COUNTERS
     stats = None
     if want_stats:
         # fused norm statistics when the launch qualifies (include/fusg.h, stats_out); else the caller falls

@@ -196,6 +196,12 @@ typedef struct fusg_conv_desc {
      * [tap][chunk32][cout_pad/32][16-column half][64 lanes][8 bf16], same tap order as `wfrag` (pack.py: frag_bf16).
      * NULL: the launch runs as F16X3. */
     const void*    wfrag_bf16;
+    /* Optional, split-K launches: `splitk_counters_len` device int32 words that are ZERO when the launch starts (the
+     * launch leaves them zero).  Given, the workgroup that finishes a tile's last K-slice sums the slices (in slice
+     * order: bit-reproducible) and applies the epilogue inside the same launch; NULL, a second kernel does. */
+    int32_t*       splitk_counters;
+    int32_t        splitk_counters_len;
+    int32_t        _pad2;
 } fusg_conv_desc;
 
 int  fusg_conv2d(const fusg_conv_desc* d, void* stream);

@@ -534,3 +534,36 @@ def test_bf16_halo_conv(cin, cout, k, stride, pad, dil, pm, H, W, pre, precision
     g2 = ops.conv(p2, _nhwc(x2), precision="bf16")
     assert ops.last_conv_kernel() in (1, 4)
     _close(g2, F.conv2d(x2, w2, padding=1), rtol=1e-5, atol=1e-5)
+
+
+def test_splitk_in_launch_combine_equals_reduce_kernel(precision, monkeypatch):
+    """The opt-in last-arriver combine of split-K launches (csrc/conv_kernel.h, splitk_arrive / splitk_combine; off by
+    default because it measured slower than the extra launch, ops.py) against the separate reduce kernel: bit-identical (same slab order), on every launch of a long, unevenly loaded sequence - a big
+    convolution keeps a second stream busy meanwhile, slab memory and counters are reused from launch to launch (stale
+    L1 / L2 lines and a wrong counter would show as a mismatch), every output word is compared."""
+    shapes = [(4, 1024, 512, 3, 1, 2, 2), (32, 128, 128, 3, 1, 4, 4), (8, 256, 128, 1, 0, 8, 8), (2, 512, 128, 3, 1, 2, 2)]
+    plans, xs = [], []
+    for i, (B, cin, cout, k, pad, H, W) in enumerate(shapes):
+        w = _rand(cout, cin, k, k, seed=40 + i, scale=1.0 / (cin * k * k) ** 0.5)
+        plans.append(pack.pack_conv(w, _rand(cout, seed=50 + i), pad=pad))
+        xs.append([_nhwc(_rand(B, cin, H, W, seed=60 + 10 * i + j)) for j in range(3)])
+    wb = _rand(128, 128, 3, 3, seed=70, scale=0.03)
+    big_plan, big_x = pack.pack_conv(wb, None, pad=1), _nhwc(_rand(8, 128, 128, 128, seed=71))
+    side = torch.cuda.Stream()
+    want = {}
+    for i, plan in enumerate(plans):                                 # default: the separate reduce kernel
+        for j, x in enumerate(xs[i]):
+            want[(i, j)] = ops.conv(plan, x).clone()
+    monkeypatch.setenv("FUSG_SPLITK_IN_LAUNCH", "1")                 # opt-in: combine inside the launch
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(60):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                ops.conv(big_plan, big_x)
+        i, j = it % len(plans), (it // 2) % 3
+        got = ops.conv(plans[i], xs[i][j])
+        bad += int(not torch.equal(got, want[(i, j)]))
+    torch.cuda.synchronize()
+    assert bad == 0
+    assert int(ops._splitk_counters(dev()).abs().sum()) == 0          # every launch left its counters zero
