@@ -48,6 +48,15 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("splitk_counters", C.c_void_p), ("splitk_counters_len", C.c_int32), ("_pad2", C.c_int32)]
 
 
+class BneckDesc(C.Structure):           # fusg_bneck_desc
+    _fields_ = [("x", Tensor), ("res", Tensor), ("dst", Tensor),
+                ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p),
+                ("w1frag", C.c_void_p), ("bias1", C.c_void_p), ("wscale1", C.c_void_p),
+                ("w2frag", C.c_void_p), ("bias2", C.c_void_p), ("wscale2", C.c_void_p),
+                ("w3frag", C.c_void_p), ("bias3", C.c_void_p), ("wscale3", C.c_void_p),
+                ("status", C.c_void_p), ("planes", C.c_int32), ("_pad", C.c_int32)]
+
+
 class PackSpec(C.Structure):            # fusg_pack_spec
     _fields_ = [(n, C.c_int32) for n in ("cout", "cin", "kh", "kw", "c0", "stride", "pad", "dil", "upsample", "cin_pad")]
 
@@ -71,6 +80,7 @@ _TP = C.POINTER(Tensor)
 _SIGS = {
     "fusg_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "fusg_conv2d_plan": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "fusg_hg_bottleneck": (C.c_int, [C.POINTER(BneckDesc), C.c_void_p]),
     "fusg_chan_stats": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_void_p]),
     "fusg_in_finalize": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fusg_ln_finalize": (C.c_int, [_TP, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -112,6 +122,7 @@ _SIGS = {
     "fusg_arch": (C.c_char_p, []),
     "fusg_sizeof_tensor": (C.c_int, []),
     "fusg_sizeof_conv_desc": (C.c_int, []),
+    "fusg_sizeof_bneck_desc": (C.c_int, []),
     "fusg_prof_enable": (None, [C.c_int]),
     "fusg_prof_reset": (None, []),
     "fusg_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -142,7 +153,8 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.fusg_sizeof_tensor() != C.sizeof(Tensor) or h.fusg_sizeof_conv_desc() != C.sizeof(ConvDesc):
+        if (h.fusg_sizeof_tensor() != C.sizeof(Tensor) or h.fusg_sizeof_conv_desc() != C.sizeof(ConvDesc)
+                or h.fusg_sizeof_bneck_desc() != C.sizeof(BneckDesc)):
             raise FusgUnavailable("libfusg.so struct layout differs from the ctypes mirror (stale build?)")
         _lib = h
     return _lib

@@ -102,6 +102,7 @@ extern "C" int fusg_last_conv_kernel(void) { return g_conv_kernel; }
 extern "C" const char* fusg_arch(void) { return "gfx950"; }
 extern "C" int fusg_sizeof_tensor(void) { return (int)sizeof(fusg_tensor); }
 extern "C" int fusg_sizeof_conv_desc(void) { return (int)sizeof(fusg_conv_desc); }
+extern "C" int fusg_sizeof_bneck_desc(void) { return (int)sizeof(fusg_bneck_desc); }
 
 extern "C" void fusg_prof_enable(int on) { g_prof_on = on != 0; }
 

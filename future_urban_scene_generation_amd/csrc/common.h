@@ -81,6 +81,12 @@ template <> struct SavedArg<const fusg_conv_desc*> {
     const fusg_conv_desc* get() const { return has ? &d : nullptr; }
 };
 
+template <> struct SavedArg<const fusg_bneck_desc*> {
+    bool has; fusg_bneck_desc d;
+    explicit SavedArg(const fusg_bneck_desc* p) : has(p != nullptr), d(p ? *p : fusg_bneck_desc{}) {}
+    const fusg_bneck_desc* get() const { return has ? &d : nullptr; }
+};
+
 // run impl(args..., stream); when a plan is recording, remember the call first
 template <class... A>
 int plan_dispatch(int (*impl)(A..., void*), void* stream, A... a) {
@@ -92,6 +98,9 @@ int plan_dispatch(int (*impl)(A..., void*), void* stream, A... a) {
     }
     return impl(a..., stream);
 }
+
+// 256 zero bytes per device, allocated on first use: where the gather of a zero-padded pixel reads (conv_igemm.hip)
+const float* zero_line();
 
 // profiler (api.hip)
 void prof_begin(int kind, hipStream_t s, double flops);

@@ -37,7 +37,7 @@ struct TileCfg { int bm, bn; };
 static const TileCfg kTiles[] = {{0, 0}, {128, 128}, {128, 64}, {128, 32}, {64, 64}, {64, 128}};
 
 // 256 zero bytes per device, allocated on first use (see ConvK::zeros)
-static const float* zero_line() {
+const float* zero_line() {
     static std::mutex mu;
     static float* z[64] = {};
     int dev = 0;

@@ -394,6 +394,42 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     return (out, stats) if want_stats else out
 
 
+def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> bool:
+    """Can this hourglass Bottleneck (packed plans c1, c2, c3 + bn1 affine) run as ONE launch (fusg_hg_bottleneck)?
+    planes 128, split-fp16 arithmetic, channels of x a multiple of 32.  FUSG_NO_BNECK=1 keeps the three launches;
+    FUSG_BNECK_MAXHW=n fuses only levels of at most n x n pixels."""
+    if (precision or PRECISION) != "f16x3" or _env_set("FUSG_NO_BNECK"):
+        return False
+    c1, c2, c3 = p["c1"], p["c2"], p["c3"]
+    if not (c1.cout == 128 and c2.cout == 128 and c3.cout == 256 and c1.kh == 1 and c2.kh == 3 and c3.kh == 1
+            and c1.c0k == x.shape[1] and x.shape[1] % 32 == 0 and c1.c1k == 0 and c2.pad == 1 and c2.stride == 1):
+        return False
+    lim = _os.environ.get("FUSG_BNECK_MAXHW")
+    return lim is None or max(x.shape[2], x.shape[3]) <= int(lim)
+
+
+def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """res + conv3(relu(conv2(relu(conv1(relu(bn1(x))))))) in one launch (fusg_hg_bottleneck; stacked_hourglass/
+    models.py:22-42).  `p`: the packed Bottleneck (pre = bn1 scale / shift, c1 / c2 with bn2 / bn3 folded, c3);
+    `res` defaults to x (no downsample conv)."""
+    res = x if res is None else res
+    b, _, h, w = x.shape
+    out = nhwc_empty(b, 256, h, w, x.device)
+    d = L.BneckDesc()
+    d.x, d.res, d.dst = desc(x), desc(res), desc(out)
+    d.pre_scale, d.pre_shift = p["pre"][0].data_ptr(), p["pre"][1].data_ptr()
+    for i, key in ((1, "c1"), (2, "c2"), (3, "c3")):
+        dev = p[key].to(x.device).dev
+        assert dev.get("wfrag") is not None and dev["wfrag_order"] == 0, key
+        setattr(d, "w%dfrag" % i, dev["wfrag"].data_ptr())
+        setattr(d, "bias%d" % i, dev["bias"].data_ptr())
+        setattr(d, "wscale%d" % i, dev["wscale"].data_ptr())
+    d.status = status_word(x.device).data_ptr()
+    d.planes = 128
+    L.check(L.lib().fusg_hg_bottleneck(C.byref(d), stream_ptr()), "hg_bottleneck")
+    return out
+
+
 def last_conv_kernel() -> int:
     """Kernel family of the last conv launch issued by this thread (fusg_last_conv_kernel): 0 generic fp32,
     1 generic split-fp16, 2 halo, 3 halo in parity-quadrant (stride-2) form, 4 tap-unit kernel (few-channel stems)."""

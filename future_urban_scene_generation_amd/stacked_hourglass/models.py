@@ -11,7 +11,8 @@ Execution is a flat sequence of libfusg launches over NHWC activations:
     is applied while the consumer 1x1 conv stages its input tile (PRE_AFFINE_RELU);
   * residual adds (``out += residual``, ``x + fc_ + score_``) are conv epilogues;
   * max-pool and ``up1 + upsample(low3)`` are single HBM-bound kernels.
-A Bottleneck is therefore 3 launches (4 with a downsample conv) instead of 10 framework ops.
+A Bottleneck is therefore 3 launches (4 with a downsample conv) instead of 10 framework ops - and, on the
+split-fp16 path, ONE launch for every block with 128 planes (fusg_hg_bottleneck: both intermediates stay in LDS).
 """
 from __future__ import annotations
 
@@ -138,6 +139,8 @@ class HourglassNet(FusedNet):
     # ------------------------------------------------------------------ execution
     @staticmethod
     def _bottleneck(p: dict, x: torch.Tensor) -> torch.Tensor:
+        if ops.bottleneck_ok(p, x):                  # planes 128, f16x3: the whole block in one launch
+            return ops.bottleneck(p, x, None if p["ds"] is None else ops.conv(p["ds"], x))
         t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU)
         t = ops.conv(p["c2"], t, act=L.ACT_RELU)
         r = x if p["ds"] is None else ops.conv(p["ds"], x)

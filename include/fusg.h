@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 105
+#define FUSG_VERSION 106
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -209,6 +209,35 @@ int  fusg_conv2d(const fusg_conv_desc* d, void* stream);
  * workspace size in bytes (0 when ksplit <= 1). */
 int64_t fusg_conv2d_plan(fusg_conv_desc* d);
 
+/*
+ * One pre-activation Bottleneck of the stacked hourglass in ONE launch (split-fp16 arithmetic, FUSG_PREC_F16X3):
+ *   out = res + conv3_1x1( relu(bn3( conv2_3x3( relu(bn2( conv1_1x1( relu(bn1(x)) ))) ))) )
+ * (stacked_hourglass/models.py:22-42; bn2 / bn3 are folded into conv1 / conv2 at pack time, bn1 is the per-channel
+ * affine `pre_scale`, `pre_shift`; `res` is x itself or the block's 1x1 `downsample` conv of x, models.py:37-38).
+ * planes must be 128 (every Bottleneck of the hourglass levels, `layer2`, `layer3` and `res`: conv1 Cin -> 128,
+ * conv2 128 -> 128, conv3 128 -> 256); x has Cin % 32 == 0 channels, res and dst 256.
+ * A workgroup owns an 8 x 8 pixel patch: conv1 is evaluated on the patch's 10 x 10 halo (zero outside the image, as
+ * conv2's zero padding requires), its output and conv2's never leave LDS (already split into fp16 pairs), so the
+ * block reads x and res once and writes out once - the three launches it replaces move 2.2x the bytes and, on the
+ * hourglass's 4 x 4 .. 16 x 16 levels, are bound by launch-to-launch latency.
+ * Weights: the `wfrag` copy (fusg_conv_desc.wfrag, wfrag_order 0) of each of the three convolutions, their `bias`
+ * [cout_pad] and `wscale` [cout_pad] arrays.  Same range contract as F16X3 launches: *status = 1 when an operand
+ * (bn1 output, or either intermediate) is outside the split's range; the caller then redoes the work in F32 with
+ * three fusg_conv2d calls.  x, res, dst: NHWC-physical f32, same n, h, w.
+ */
+typedef struct fusg_bneck_desc {
+    fusg_tensor x, res, dst;
+    const float* pre_scale;      /* [Cin] bn1 as y = x * scale + shift, then ReLU               */
+    const float* pre_shift;
+    const void*  w1frag; const float* bias1; const float* wscale1;     /* conv1 (+bn2): Cin -> 128, 1x1  */
+    const void*  w2frag; const float* bias2; const float* wscale2;     /* conv2 (+bn3): 128 -> 128, 3x3  */
+    const void*  w3frag; const float* bias3; const float* wscale3;     /* conv3: 128 -> 256, 1x1         */
+    int32_t*     status;
+    int32_t      planes;         /* 128 */
+    int32_t      _pad;
+} fusg_bneck_desc;
+int fusg_hg_bottleneck(const fusg_bneck_desc* d, void* stream);
+
 /* Load-time weight pre-packing on the HOST (no device work): everything fusg_conv_desc needs for one nn.Conv2d-style
  * filter weight[cout][cin][kh][kw] (torch layout, correlation form) whose input channels come from one source (c0 = cin)
  * or from two concatenated sources (the first c0 channels from src0: torch.cat([x, skip], 1) fused into the gather).
@@ -363,13 +392,14 @@ const char* fusg_last_error(void);
  * 0 generic fp32, 1 generic split-fp16, 2 halo, 3 halo in parity-quadrant form (stride 2), 4 tap-unit kernel
  * (few-channel stems), 5 halo kernel in single-pass bf16; -1 none yet. */
 enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3,
-       FUSG_CONV_TAPUNIT = 4, FUSG_CONV_HALO_BF16 = 5 };
+       FUSG_CONV_TAPUNIT = 4, FUSG_CONV_HALO_BF16 = 5, FUSG_CONV_BNECK = 6 /* fusg_hg_bottleneck */ };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their
  * struct mirrors. */
 int         fusg_sizeof_tensor(void);
 int         fusg_sizeof_conv_desc(void);
+int         fusg_sizeof_bneck_desc(void);
 /* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
  * kind 0 = conv implicit-GEMM kernel.  Disabled by default; enabling makes launches record two
  * events each.  fusg_prof_read synchronises the recorded events and returns totals since reset. */

@@ -567,3 +567,87 @@ def test_splitk_in_launch_combine_equals_reduce_kernel(precision, monkeypatch):
     torch.cuda.synchronize()
     assert bad == 0
     assert int(ops._splitk_counters(dev()).abs().sum()) == 0          # every launch left its counters zero
+
+
+# ---- fused hourglass Bottleneck (fusg_hg_bottleneck) -----------------------------------------------------------------
+def _bneck_params(cin, seed=0, scale=1.0):
+    """A pre-activation Bottleneck with 128 planes as the hourglass packs it: bn1 affine, conv1 + bn2, conv2 + bn3, conv3."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)                                                       # noqa: E731
+    s1, h1 = torch.rand(cin, generator=g) + 0.5, rn(cin) * 0.2
+    w1, b1 = rn(128, cin, 1, 1) * scale / cin ** 0.5, rn(128) * 0.1
+    w2, b2 = rn(128, 128, 3, 3) * scale / 1152 ** 0.5, rn(128) * 0.1
+    w3, b3 = rn(256, 128, 1, 1) * scale / 128 ** 0.5, rn(256) * 0.1
+    p = {"pre": (s1.to(dev()), h1.to(dev())), "c1": pack.pack_conv(w1, b1).to(dev()),
+         "c2": pack.pack_conv(w2, b2, pad=1).to(dev()), "c3": pack.pack_conv(w3, b3).to(dev()), "ds": None}
+    return p, (s1, h1, w1, b1, w2, b2, w3, b3)
+
+
+def _bneck_ref(x, res, prm):
+    s1, h1, w1, b1, w2, b2, w3, b3 = (t.double() for t in prm)
+    t = F.relu(x.double() * s1.view(1, -1, 1, 1) + h1.view(1, -1, 1, 1))
+    t = F.relu(F.conv2d(t, w1, b1))
+    t = F.relu(F.conv2d(t, w2, b2, padding=1))
+    return F.conv2d(t, w3, b3) + res.double()
+
+
+def _bneck_unfused(p, x, res):
+    t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU, precision="f16x3")
+    t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision="f16x3")
+    return ops.conv(p["c3"], t, res0=res, precision="f16x3")
+
+
+@pytest.mark.parametrize("B,cin,H,W,own_res", [(2, 256, 8, 8, False), (3, 256, 4, 4, False), (2, 256, 16, 16, False),
+                                                 (1, 256, 64, 64, False), (2, 128, 32, 32, True), (1, 256, 12, 20, False),
+                                                 (2, 64, 5, 9, True)])
+def test_hg_bottleneck_fused(B, cin, H, W, own_res, precision):
+    """One-launch Bottleneck against an fp64 reference and against the three launches it replaces (same arithmetic,
+    different summation order): error relative to the output's largest magnitude <= 2e-6 (observed ~3e-7), and no
+    worse than 2x the three-launch path's."""
+    if precision != "f16x3":
+        pytest.skip("the fused block exists on the split-fp16 path only")
+    from conftest import record
+    p, prm = _bneck_params(cin, seed=21)
+    x = _rand(B, cin, H, W, seed=22)
+    res = _rand(B, 256, H, W, seed=23) if own_res else x
+    assert own_res or cin == 256
+    ref = _bneck_ref(x, res, prm)
+    xin = _nhwc(x)
+    rin = _nhwc(res) if own_res else xin
+    assert ops.bottleneck_ok(p, xin)
+    got = ops.bottleneck(p, xin, rin)
+    assert ops.last_conv_kernel() == 6
+    assert not ops.range_exceeded(dev())
+    un = _bneck_unfused(p, xin, rin)
+    den = float(ref.abs().max())
+    e_f = float((got.cpu().double() - ref).abs().max()) / den
+    e_u = float((un.cpu().double() - ref).abs().max()) / den
+    record("bneck_fused_rel_err", e_f)
+    record("bneck_unfused_rel_err", e_u)
+    assert e_f <= 2e-6 and e_f <= 2 * e_u + 1e-7, (e_f, e_u)
+
+
+def test_hg_bottleneck_fused_range_and_scale(precision):
+    """Range contract of the fused block: an input holding 1e5 raises the status word (on bn1's output), a conv1
+    whose weights push the FIRST INTERMEDIATE past 2^15 raises it too, and operands 100x smaller than usual keep the
+    fp32-class error."""
+    if precision != "f16x3":
+        pytest.skip("split-fp16 path only")
+    p, prm = _bneck_params(256, seed=31)
+    x = _rand(2, 256, 8, 8, seed=32)
+    xin = _nhwc(x)
+    ops.bottleneck(p, xin)
+    assert not ops.range_exceeded(dev())
+    xb = x.clone()
+    xb[1, 7, 3, 3] = 1e5
+    ops.bottleneck(p, _nhwc(xb))
+    assert ops.range_exceeded(dev())
+    p2, _ = _bneck_params(256, seed=31, scale=3e4)              # conv1's output ~ 2e4 * N(0, 1): many |t1| >= 2^15
+    ops.bottleneck(p2, xin)
+    assert ops.range_exceeded(dev())
+    p3, prm3 = _bneck_params(256, seed=33, scale=1e-2)
+    ref = _bneck_ref(x * 1e-2, x * 1e-2, prm3)
+    got = ops.bottleneck(p3, _nhwc(x * 1e-2))
+    assert not ops.range_exceeded(dev())
+    t = F.relu(x.double() * 1e-2 * prm3[0].double().view(1, -1, 1, 1) + prm3[1].double().view(1, -1, 1, 1))
+    assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), float(t.abs().max())

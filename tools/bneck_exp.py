@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Fused hourglass Bottleneck (fusg_hg_bottleneck) against the three launches it replaces, per hourglass level
+(GPU box, analysis tool): sustained ms per block, TFLOP/s on the three convolutions' own FLOPs.
+    python tools/bneck_exp.py [B]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from future_urban_scene_generation_amd import _lib as L  # noqa: E402
+from future_urban_scene_generation_amd import ops, pack  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, seconds=0.6):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n, t0 = 0, time.time()
+    e0.record()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        n += 20
+        torch.cuda.synchronize()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s: torch.randn(*s, generator=g)                                                       # noqa: E731
+    cin = 256
+    p = {"pre": ((torch.rand(cin, generator=g) + 0.5).to(dev), (rn(cin) * 0.2).to(dev)),
+         "c1": pack.pack_conv(rn(128, cin, 1, 1) / cin ** 0.5, rn(128) * 0.1).to(dev),
+         "c2": pack.pack_conv(rn(128, 128, 3, 3) / 1152 ** 0.5, rn(128) * 0.1, pad=1).to(dev),
+         "c3": pack.pack_conv(rn(256, 128, 1, 1) / 128 ** 0.5, rn(256) * 0.1).to(dev), "ds": None}
+
+    def unfused(x):
+        t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU, precision="f16x3")
+        t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision="f16x3")
+        return ops.conv(p["c3"], t, res0=x, precision="f16x3")
+
+    for hw in (128, 64, 32, 16, 8, 4):
+        if hw == 128 and B > 8:
+            continue
+        x = ops.as_nhwc(rn(B, cin, hw, hw).to(dev))
+        fl = 2.0 * B * hw * hw * (cin * 128 + 1152 * 128 + 128 * 256)
+        a = timed(lambda: ops.bottleneck(p, x))
+        b = timed(lambda: unfused(x))
+        print(f"B={B} {hw:3d}x{hw:<3d} fused {a * 1e3:8.1f} us {fl / a / 1e9:6.1f} TF | 3 launches {b * 1e3:8.1f} us {fl / b / 1e9:6.1f} TF | x{b / a:.2f}",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
