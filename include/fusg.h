@@ -361,6 +361,25 @@ int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream
  * the pixel lies outside that rectangle; masks u8 [V, 1, H, W] (non-zero = paste), geom as in fusg_icn_inputs. */
 int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream);
 
+/* ---- pose fit ------------------------------------------------------------------------------- */
+/*
+ * The reference's pose fit ("CamPoseCalib": Levenberg-Marquardt on a Rodrigues vector + translation, utils/cpc.py:45-139
+ * with the iteration / lambda policies of utils/pnp_utils.py:8-41), batched: one GPU thread per (vehicle, start).
+ * utils/pnp_utils.py:43-115 (cpc_rodr_4_angles) runs it from four fixed start rotations per vehicle, each run ~52
+ * iterations of 12 autograd backward passes on the host (5 s per vehicle measured); here all vehicles and starts of a
+ * frame are one launch.  Reference behaviour kept: float32; only the first min(6, npoints) points enter the Jacobian
+ * (cpc.py:30) while all points enter the cost and the returned error; every step is accepted; the loop ends when
+ * iteration > max_iter (reference: 50).  Device arrays, row-major:
+ *   points3d [B][npoints][3], points2d [B][npoints][2], focals [B][2], centers [B][2]   (npoints <= 16)
+ *   rvec0 [nstarts][3], tvec0 [3]                                                       start parameters
+ *   rvec, tvec [B][nstarts][3], err [B][nstarts]   (err = mean squared residual of the last evaluated iteration)
+ * The choice of the best start and the sign flip of pnp_utils.py:117-130 are a few host operations on these outputs
+ * (future_urban_scene_generation_amd/utils/pnp_utils.py).
+ */
+int fusg_pnp_cpc(const float* points3d, const float* points2d, const float* focals, const float* centers,
+                 const float* rvec0, const float* tvec0, int32_t B, int32_t npoints, int32_t nstarts, int32_t max_iter,
+                 float* rvec, float* tvec, float* err, void* stream);
+
 /* ---- recorded passes ------------------------------------------------------------------------ */
 /* A fusg_plan records the launch sequence of one pass (every fusg_* launch made by the recording thread between
  * fusg_plan_begin and fusg_plan_end, with its descriptors copied and its stream remembered; the calls also execute)
