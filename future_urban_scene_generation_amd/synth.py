@@ -18,7 +18,7 @@ import torch
 
 # Per-net gains chosen so that activations stay O(1) through the whole depth with random weights
 # (otherwise tanh saturates / images turn constant and SSIM against the reference is meaningless).
-_CONV_GAIN = {"hg": 0.7, "icn": 1.4, "vunet": 0.7, "edge": 1.4, "inpaint": 1.4}
+_CONV_GAIN = {"hg": 0.7, "icn": 1.4, "vunet": 0.7, "edge": 1.4, "inpaint": 1.4, "vgg": 1.4142135}
 
 
 def _gen(net: str, key: str, seed: int) -> torch.Generator:
@@ -37,7 +37,7 @@ def _uniform(shape, lo, hi, g):
 
 def synth_state_dict(net: str, schema: Mapping[str, Tuple[Sequence[int], str]], seed: int = 0
                      ) -> "OrderedDict[str, torch.Tensor]":
-    """Build a full state_dict for ``net`` in {'hg','icn','vunet','edge','inpaint'}.
+    """Build a full state_dict for ``net`` in {'hg','icn','vunet','edge','inpaint','vgg'}.
 
     ``schema`` maps state_dict key -> (shape, dtype-name), in state_dict order (the reference's
     own schema is shipped in the package, schemas/schema_*.json; the HIP-backed modules expose the
@@ -66,6 +66,8 @@ def synth_state_dict(net: str, schema: Mapping[str, Tuple[Sequence[int], str]], 
         elif leaf in ("weight", "weight_orig") and len(shape) == 4:
             fan_in = shape[1] * shape[2] * shape[3]
             t = _normal(shape, gain / fan_in ** 0.5, g)
+        elif leaf == "weight" and len(shape) == 2:             # Linear (the CAD classifier's head)
+            t = _normal(shape, gain / shape[1] ** 0.5, g)
         elif leaf == "weight" and len(shape) == 1:             # BatchNorm scale
             t = _uniform(shape, 0.5, 1.5, g)
         elif leaf == "weight_v" and len(shape) == 4:           # weight_norm direction

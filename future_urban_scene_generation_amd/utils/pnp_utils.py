@@ -106,7 +106,7 @@ def cpc_rodr_4_angles_batch(focals, centers, keypoints_pred, kpoints3D, device="
     f = np.broadcast_to(np.asarray(focals, np.float32).reshape(-1, 2), (b, 2))
     c = np.broadcast_to(np.asarray(centers, np.float32).reshape(-1, 2), (b, 2))
     dev = torch.device(device)
-    rv, tv, er = cpc_fit_device(*(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (f, c, p2, p3)))
+    rv, tv, er = cpc_fit_device(*(torch.from_numpy(np.array(a, dtype=np.float32, order="C")).to(dev) for a in (f, c, p2, p3)))
     rv, tv, er = rv.cpu().numpy(), tv.cpu().numpy(), er.cpu().numpy()
     return [select_and_flip(rv[i], tv[i], er[i]) for i in range(b)]
 
