@@ -384,7 +384,7 @@ def main():
                     ("single-pass bf16 on the halo-kernel layers: 1 matrix FLOP per algorithmic FLOP there (peak = dense bf16 MFMA "
                      "2500 TFLOP/s); the hourglass and the non-halo layers still cost 3")
             else:
-                kern, peak, note = "fusg::conv_halo_h3 + conv_tapunit_h3 + conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
+                kern, peak, note = "fusg::conv_halo_h3 + hg_bneck_h3 + conv_tapunit_h3 + conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
                     ("split-fp16: every fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh'); peak = dense "
                      "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
             roofline = {"bound": "mfma", "kernel": kern,

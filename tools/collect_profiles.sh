@@ -33,6 +33,8 @@ python3 tools/hbm_traffic.py $out/pmc_f $out/pmc_w > $out/${tag}_hbm_traffic_cfg
 cp profiles/hbm_traffic_latest.json $out/hbm_traffic_latest.json
 python3 tools/mfma_util.py $out/pmc_m > $out/${tag}_mfma_util.txt
 echo "pmc done"
+timeout -k 10 200 python tools/bneck_exp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_bneck_fused_vs_3_launches.txt
+timeout -k 10 200 python tools/issue_time.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_replay_issue_vs_done.jsonl
 FUSG_STREAMS=0 timeout -k 10 300 python tools/layer_profile.py --top 90 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile.txt
 timeout -k 10 400 python tools/halo_exp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_halo_layers_sustained.txt
 rm -rf $out/stats $out/pmc_f $out/pmc_w $out/pmc_m

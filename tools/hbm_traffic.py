@@ -17,9 +17,9 @@ import os
 import sys
 
 
-CONV_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "conv_splitk_reduce")     # every dispatch a fusg_conv2d call makes
+CONV_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "conv_splitk_reduce", "hg_bneck")     # every dispatch a fusg_conv2d call makes
 # one fusg_conv2d call = one launch, except split-K launches, which add their reduce dispatch: calls = main dispatches
-MAIN_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit")
+MAIN_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "hg_bneck")
 
 
 def load(d, counter):

@@ -50,6 +50,21 @@ def main():
                      f"{h}x{w}", m, plan.k_pad, e0.elapsed_time(e1), fl))
         return out
 
+    orig_b = ops.bottleneck
+
+    def timed_b(p, x, res=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_b(p, x, res)
+        e1.record()
+        e1.synchronize()
+        b, c, h, w = x.shape
+        m = b * h * w
+        rows.append((net[0], f"bottleneck {c}->128->128->256 fused", f"{h}x{w}", m, c + 1152 + 128, e0.elapsed_time(e1),
+                     2.0 * m * (c * 128 + 1152 * 128 + 128 * 256)))
+        return out
+
+    ops.bottleneck = timed_b
     ops.conv = timed
     import future_urban_scene_generation_amd.stacked_hourglass.models as m1
     import future_urban_scene_generation_amd.warp_learn.models as m2

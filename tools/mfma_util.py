@@ -12,7 +12,7 @@ import sys
 
 
 def family(name):
-    for k in ("conv_halo_h3", "conv_tapunit_h3", "conv_igemm_h3", "conv_igemm_f32", "conv_splitk_reduce"):
+    for k in ("conv_halo_h3", "conv_tapunit_h3", "conv_igemm_h3", "conv_igemm_f32", "conv_splitk_reduce", "hg_bneck_h3"):
         if k in name:
             return k
     return name.split("(")[0].split("::")[-1][:28]
@@ -33,7 +33,7 @@ def main():
     rows = []
     for fam, c in tot.items():
         cu, busy = c.get("SQ_BUSY_CU_CYCLES", 0.0), c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-        if fam.startswith("conv_") and fam != "conv_splitk_reduce":
+        if (fam.startswith("conv_") or fam == "hg_bneck_h3") and fam != "conv_splitk_reduce":
             conv_busy += busy
             conv_cu += cu
         rows.append((cu, fam, len(nd[fam]), busy / (4 * cu) if cu else 0.0, c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)))
