@@ -144,6 +144,46 @@ class VehiclePipeline:
                 rec.dependency(main.cuda_stream, st.cuda_stream)
         return out
 
+    def _side(self, name: str, fn):
+        """Run fn() on the side stream `name`, forked from the CURRENT stream (what is queued there now is finished
+        before fn's launches start); returns (fn's result, join): join() makes the current stream wait for the side
+        stream.  Used for the VUnet's two independent encoders: the shape encoder (forward_dec_up) does not depend
+        on the appearance half (forward_enc_up -> forward_enc_down), so the VUnet's chain of dependent launches - the
+        longest of the pass - is a third shorter.  FUSG_VUNET_SPLIT=0 (or FUSG_STREAMS=0) keeps one stream."""
+        from . import ops
+        if (os.environ.get("FUSG_STREAMS", "1") == "0" or os.environ.get("FUSG_VUNET_SPLIT", "1") == "0"
+                or self.device.type != "cuda"):
+            return fn(), (lambda: None)
+        cur = torch.cuda.current_stream(self.device)
+        pool = self.__dict__.setdefault("_streams", {})
+        st = pool.get(name)
+        if st is None:
+            st = pool[name] = torch.cuda.Stream(device=self.device, priority=-1)
+        rec = ops.RECORDER
+        if rec is None:
+            st.wait_stream(cur)
+        else:
+            rec.dependency(st.cuda_stream, cur.cuda_stream)
+        with torch.cuda.stream(st):
+            res = fn()
+
+        def tensors(o):
+            if torch.is_tensor(o):
+                yield o
+            elif isinstance(o, (list, tuple)):
+                for q in o:
+                    yield from tensors(q)
+
+        def join():
+            if rec is None:
+                cur.wait_stream(st)
+            else:
+                rec.dependency(cur.cuda_stream, st.cuda_stream)
+            for t in tensors(res):
+                t.record_stream(cur)
+
+        return res, join
+
     def compile(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> "CompiledPass":
         """Record one crop pass for inputs of `batch`'s shapes into a fusg_plan and return the object that replays it:
         `compiled.run(batch, vehicle_seeds)` gives what `self.run` gives, with one library call instead of ~370 (the
@@ -217,9 +257,12 @@ class VehiclePipeline:
 
         def vunet():
             vu = self.vunet
-            eo, es = vu.forward_enc_up(batch["vu_x"])                  # trajectory_inference.py:230-233
+            # trajectory_inference.py:230-233; the shape encoder runs beside the appearance half (it draws no noise,
+            # so the host-side draw order is the reference's either way)
+            (do, ds), join = self._side("vunet_shape", lambda: vu.forward_dec_up(batch["vu_y"]))
+            eo, es = vu.forward_enc_up(batch["vu_x"])
             mu_app, _ = vu.forward_enc_down(eo, es)
-            do, ds = vu.forward_dec_up(batch["vu_y"])
+            join()
             xt, _, _ = vu.forward_dec_down(do, ds, mu_app)
             return {"vunet_u8": ops.to_image_u8(xt)}
 
