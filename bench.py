@@ -70,6 +70,10 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
     ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
     ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
+    ap.add_argument("--broadcast-weights", action="store_true",
+                    help="N > 1: only rank 0 builds the (synthetic) checkpoints, the others receive them through "
+                         "pipeline.broadcast_state_dicts (RCCL broadcast of one flat blob per network) instead of "
+                         "rebuilding them from the seed")
     ap.add_argument("--replay", action="store_true",
                     help="issue each pass as ONE recorded-plan replay (fusg_plan) instead of ~370 launches from Python: "
                          "matters at small --batch, where the interpreter bounds the pass")
@@ -264,7 +268,16 @@ def main():
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, shard_range, synth_batch
 
     torch.set_grad_enabled(False)
-    pipe = VehiclePipeline(dev, inpaint=args.inpaint)
+    sds, bcast_ms = None, None
+    if args.broadcast_weights and world > 1:
+        from future_urban_scene_generation_amd.pipeline import broadcast_state_dicts, load_schema
+        from future_urban_scene_generation_amd.synth import synth_state_dict
+        nets = ("hg", "icn", "vunet") + (("edge", "inpaint") if args.inpaint else ())
+        mine = {n: synth_state_dict(n, load_schema(n), 0) for n in nets} if rank == 0 else None
+        t_b = time.perf_counter()
+        sds = broadcast_state_dicts(mine, nets=nets, device=coll_dev)
+        bcast_ms = (time.perf_counter() - t_b) * 1e3
+    pipe = VehiclePipeline(dev, inpaint=args.inpaint, state_dicts=sds)
     if args.vehicles:
         # strong scaling (BASELINE configs[3]: one frame's vehicles sharded over the ranks): this rank's contiguous shard
         lo, hi = shard_range(args.vehicles, rank, world)
@@ -477,11 +490,13 @@ def main():
             line["dist_backend"] = dist.get_backend()
             line["per_rank_crops_per_s"] = h.get("per_rank_crops_per_s")
             line["gather_enqueue_ms_per_step"] = h.get("gather_enqueue_ms_per_step")
+            line["weights"] = ("broadcast from rank 0 (%.0f ms, one flat blob per network)" % bcast_ms) if bcast_ms is not None \
+                else "every rank builds them from the seed (--broadcast-weights: RCCL broadcast from rank 0)"
         line.update(extra)
         if h.get("power") is not None:
             line["power"] = h["power"]
         line["settle_steps"] = h["settle_steps"]
-        line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch"
+        line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch (+ one for the VUnet's shape encoder)"
         line["issue"] = "recorded plan replay (fusg_plan_run)" if args.replay else "eager (one ctypes call per launch)"
         print(json.dumps(line), flush=True)
     if world > 1:

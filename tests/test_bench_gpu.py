@@ -32,7 +32,8 @@ def test_bench_gpus2_self_spawn():
     # strong-scaling mode (BASELINE configs[3] shape): 5 vehicles over 2 ranks, ragged shards
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--vehicles", "5", "--steps", "2",
                         "--warmup", "1", "--res", "128", "--settle-s", "0", "--no-cpu-baseline", "--no-clip", "--no-prof",
-                        "--precision", "f16x3"], env=env, capture_output=True, text=True, timeout=900)
+                        "--precision", "f16x3", "--broadcast-weights"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "5 vehicles" in line["config"]["workload"]
+    assert line["weights"].startswith("broadcast from rank 0")

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from future_urban_scene_generation_amd.pipeline import gather_in_order, shard_range
+from future_urban_scene_generation_amd.pipeline import broadcast_state_dicts, gather_in_order, load_schema, shard_range
 
 
 def test_shard_range_partitions():
@@ -107,3 +107,37 @@ def test_vehicle_noise_streams_are_shard_invariant():
     assert all(torch.equal(a, b) for a, b in zip(ref, got))
     with pytest.raises(ValueError):
         draw([1, 2, 3], 2)
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from future_urban_scene_generation_amd.synth import synth_state_dict
+        nets = ("hg", "icn")
+        mine = {n: synth_state_dict(n, load_schema(n), 3) for n in nets} if rank == 0 else None
+        got = broadcast_state_dicts(mine, nets=nets)
+        want = {n: synth_state_dict(n, load_schema(n), 3) for n in nets}      # what rank 0 holds
+        ok = all(list(got[n].keys()) == list(want[n].keys()) and
+                 all(got[n][k].dtype == want[n][k].dtype and torch.equal(got[n][k], want[n][k]) for k in want[n]) for n in nets)
+        q.put((rank, ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_from_rank0():
+    """Start-up collective of SURVEY 8(e): only rank 0 holds the checkpoints; after the broadcast every rank has
+    bit-identical state_dicts in the reference's key order and dtypes (incl. the hourglass's int64 BatchNorm counters)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}

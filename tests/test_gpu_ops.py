@@ -651,3 +651,23 @@ def test_hg_bottleneck_fused_range_and_scale(precision):
     assert not ops.range_exceeded(dev())
     t = F.relu(x.double() * 1e-2 * prm3[0].double().view(1, -1, 1, 1) + prm3[1].double().view(1, -1, 1, 1))
     assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), float(t.abs().max())
+
+
+def test_hg_bottleneck_fused_random_shapes(precision):
+    """Seeded sweep over image sizes that do not divide into 8 x 8 patches, batch sizes and input widths: the fused
+    block equals the three launches to 1e-6 of the output's range everywhere (same arithmetic, different order)."""
+    if precision != "f16x3":
+        pytest.skip("split-fp16 path only")
+    rng = np.random.default_rng(5)
+    for it in range(16):
+        cin = int(rng.choice([32, 64, 128, 256, 288]))
+        B, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        p, _ = _bneck_params(cin, seed=100 + it)
+        x = _rand(B, cin, H, W, seed=200 + it)
+        res = _rand(B, 256, H, W, seed=300 + it)
+        xin, rin = _nhwc(x), _nhwc(res)
+        got = ops.bottleneck(p, xin, rin)
+        un = _bneck_unfused(p, xin, rin)
+        err = float((got - un).abs().max() / un.abs().max())
+        assert err < 1e-6, (cin, B, H, W, err)
+    assert not ops.range_exceeded(dev())
