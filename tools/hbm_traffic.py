@@ -48,8 +48,8 @@ def main():
     import datetime
     out = {"conv_launches": launches, "conv_dispatches": fn["conv"], "conv_fetch_bytes_total": fetch_b, "conv_write_bytes_total": write_b,
            "conv_bytes_per_launch": (fetch_b + write_b) / max(1, launches),
-           "definition": "HBM bytes of every dispatch a fusg_conv2d call makes (generic / halo / tap-unit kernels + split-K "
-                         "reduce), per fusg_conv2d call - the same unit as bench.py's roofline.achieved",
+           "definition": "HBM bytes of every dispatch a conv call (fusg_conv2d / fusg_hg_bottleneck) makes (generic / halo / tap-unit / "
+                         "fused-bottleneck kernels + split-K reduce), per conv call - the same unit as bench.py's roofline.achieved",
            "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide streaming reads), WRITE_SIZE KiB x1024",
            "collected": datetime.date.today().isoformat() + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of "
                         "bench.py --precision f16x3 (serialised branches)",
