@@ -37,25 +37,29 @@ struct BneckK {
     int B, H, W, Cin, tiles_x, tiles_y;
 };
 
-constexpr int BN_P = 128;                 // planes
 constexpr int BN_HP = 100;                // 10 x 10 halo pixels
 constexpr int BN_SROWS = 112;             // ... as 7 row groups of 16
-constexpr size_t BN_LDS = (size_t)(2 * BN_SROWS * 32 + 2 * 4 * BN_HP * 32) * sizeof(_Float16);   // 65536
+constexpr size_t bneck_lds(int planes) { return (size_t)(2 * BN_SROWS * 32 + 2 * (planes / 32) * BN_HP * 32) * sizeof(_Float16); }   // 64 KiB at 128
 
-typedef h8 WFrag[2][2];                   // [16-column half][hi | lo]
+template <int CT> struct WFrag { h8 f[CT][2]; };      // [16-column tile][hi | lo]
 
 __device__ __forceinline__ f32x4 mfma16(const h8 a, const h8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// P = planes (128: every block of the hourglass levels; 64: the `layer1` block).  The four waves split the output
+// channels: CT1 = P / 64 16-channel tiles of conv1 / conv2 per wave, CT3 = P / 32 of conv3's 2 P channels.
+template <int P>
 __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
+    constexpr int NCH = P / 32;                          // 32-channel chunks of the intermediates
+    constexpr int CT1 = P / 64, CT3 = P / 32;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     _Float16* Sh = smem_h;                              // conv1's operand, one 32-channel chunk: [112][32]
     _Float16* Sl = Sh + BN_SROWS * 32;
-    _Float16* Th = Sl + BN_SROWS * 32;                  // conv1's output on the halo: [4 chunks][100][32]
-    _Float16* Tl = Th + 4 * BN_HP * 32;
-    _Float16* Uh = Th;                                  // conv2's output on the patch: [4 chunks][64][32] (overlays T)
-    _Float16* Ul = Th + 4 * 64 * 32;
+    _Float16* Th = Sl + BN_SROWS * 32;                  // conv1's output on the halo: [NCH chunks][100][32]
+    _Float16* Tl = Th + NCH * BN_HP * 32;
+    _Float16* Uh = Th;                                  // conv2's output on the patch: [NCH chunks][64][32] (overlays T)
+    _Float16* Ul = Th + NCH * 64 * 32;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lp = lane & 15, lg = lane >> 4;           // pixel of the fragment, 8-k slot
@@ -114,23 +118,29 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
             if ((sexist >> j) & 1u) { *(h4*)(Sh + soff[j]) = hi; *(h4*)(Sl + soff[j]) = lo; }
         }
     };
-    // weight fragments of (slab, 32-column tile n32) in a panel of nt32 tiles per slab
-    auto load_w = [&](WFrag& F, const _Float16* w, int slab, int nt32, int n32) {
-        const _Float16* p = w + ((long)(slab * nt32 + n32) * 4) * 512 + lane * 8;
-        F[0][0] = *(const h8*)(p);
-        F[0][1] = *(const h8*)(p + 512);
-        F[1][0] = *(const h8*)(p + 1024);
-        F[1][1] = *(const h8*)(p + 1536);
+    // weight fragments of 16-column tiles gct0 .. gct0 + CT - 1 of slab `slab` in a panel of nt32 32-column tiles per slab
+    // ([slab][nt32][16-column half][hi | lo][64 lanes][8 halves], pack.frag_f16x3)
+    auto load_w = [&](auto& F, const _Float16* w, int slab, int nt32, int gct0) {
+        constexpr int CT = sizeof(F.f) / sizeof(F.f[0]);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int gct = gct0 + j;
+            const _Float16* p = w + ((long)((slab * nt32 + (gct >> 1)) * 2 + (gct & 1)) * 2) * 512 + lane * 8;
+            F.f[j][0] = *(const h8*)(p);
+            F.f[j][1] = *(const h8*)(p + 512);
+        }
     };
 
-    f32x4 acc1[7][2];
+    f32x4 acc1[7][CT1];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CT1; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sfrag = lp * 32 + ((lg ^ (((lp >> 2) & 1) << 1)) << 3);      // + rg * 512: this lane's fragment in S / U
-    auto compute1 = [&](const WFrag& F) {
-        const h8 bs0 = scale_m11(F[0][0]), bs1 = scale_m11(F[1][0]);
+    auto compute1 = [&](const WFrag<CT1>& F) {
+        h8 bs[CT1];
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) bs[j] = scale_m11(F.f[j][0]);
 #pragma unroll
         for (int i0 = 0; i0 < 7; i0 += 2) {
             const int n = i0 + 1 < 7 ? 2 : 1;
@@ -143,42 +153,44 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     if (i < n) {
-                        acc1[i0 + i][0] = mfma16(term == 0 ? F[0][0] : term == 1 ? F[0][1] : bs0, term == 2 ? xl[i] : xh[i], acc1[i0 + i][0]);
-                        acc1[i0 + i][1] = mfma16(term == 0 ? F[1][0] : term == 1 ? F[1][1] : bs1, term == 2 ? xl[i] : xh[i], acc1[i0 + i][1]);
+#pragma unroll
+                        for (int j = 0; j < CT1; ++j)
+                            acc1[i0 + i][j] = mfma16(term == 0 ? F.f[j][0] : term == 1 ? F.f[j][1] : bs[j], term == 2 ? xl[i] : xh[i], acc1[i0 + i][j]);
                     }
         }
     };
 
     const int nch1 = k.Cin >> 5;
-    WFrag wA, wB;
+    WFrag<CT1> wA, wB;
     issue(0);
-    load_w(wA, k.w1, 0, 4, wave);
+    load_w(wA, k.w1, 0, NCH, wave * CT1);
     for (int c = 0; c < nch1; c += 2) {
         commit();
         __syncthreads();
-        if (c + 1 < nch1) { issue(c + 1); load_w(wB, k.w1, c + 1, 4, wave); }
+        if (c + 1 < nch1) { issue(c + 1); load_w(wB, k.w1, c + 1, NCH, wave * CT1); }
         compute1(wA);
         __syncthreads();                                        // every wave is done with this chunk's image
         if (c + 1 >= nch1) break;
         commit();
         __syncthreads();
-        if (c + 2 < nch1) { issue(c + 2); load_w(wA, k.w1, c + 2, 4, wave); }
+        if (c + 2 < nch1) { issue(c + 2); load_w(wA, k.w1, c + 2, NCH, wave * CT1); }
         compute1(wB);
         __syncthreads();
     }
 
     // first weights of conv2 on their way while conv1's result is written to T
-    WFrag w0, w1, w2;
-    load_w(w0, k.w2, 0, 4, wave);
-    load_w(w1, k.w2, 4, 4, wave);
-    // this lane's 4 channels of a 16-channel tile: slot and offset inside the 32-channel chunk `wave`
+    WFrag<CT1> w0, w1, w2;
+    load_w(w0, k.w2, 0, NCH, wave * CT1);                       // step 0 = (chunk 0, tap 0)
+    load_w(w1, k.w2, NCH, NCH, wave * CT1);                     // step 1 = (chunk 0, tap 1): slab tap * NCH + chunk
+    // this lane's 4 channels of 16-channel tile gct: chunk gct >> 1, slot 2 (gct & 1) + (lg >> 1), halves (lg & 1) * 4
     const int sub = (lg & 1) << 2;
     {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int n0 = wave * 32 + ct * 16 + lg * 4;
+        for (int j = 0; j < CT1; ++j) {
+            const int gct = wave * CT1 + j;
+            const int n0 = gct * 16 + lg * 4;
             const f32x4 bias = *(const f32x4*)(k.b1 + n0), wsc = *(const f32x4*)(k.s1 + n0);
-            const int g = ct * 2 + (lg >> 1);
+            const int g = (gct & 1) * 2 + (lg >> 1);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 const int pix = i * 16 + lp;
@@ -187,11 +199,11 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
                 const bool ok = pix < BN_HP && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float y = fmaxf(fmaf(acc1[i][ct][r], wsc[r], bias[r]), 0.f); v[r] = ok ? y : 0.f; }
+                for (int r = 0; r < 4; ++r) { const float y = fmaxf(fmaf(acc1[i][j][r], wsc[r], bias[r]), 0.f); v[r] = ok ? y : 0.f; }
                 h4 hi, lo;
                 split4(v, ninf, hi, lo, amax);
                 if (pix < BN_HP) {
-                    const int o = (wave * BN_HP + pix) * 32 + ((g ^ ((hy & 1) << 1)) << 3) + sub;
+                    const int o = ((gct >> 1) * BN_HP + pix) * 32 + ((g ^ ((hy & 1) << 1)) << 3) + sub;
                     *(h4*)(Th + o) = hi;
                     *(h4*)(Tl + o) = lo;
                 }
@@ -201,63 +213,64 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     __syncthreads();
 
     // ------------------------------------------------------------------ conv2: 3x3 over T
-    f32x4 acc2[4][2];
+    f32x4 acc2[4][CT1];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CT1; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int prow = lp >> 3, pcol = lp & 7;                    // the lane's pixel inside a row group: 2 rows x 8 columns
     const int tfrag = (prow * 10 + pcol) * 32;                  // + rg * 640
-    auto compute2 = [&](const WFrag& F, int c, int tap) {
+    auto compute2 = [&](const WFrag<CT1>& F, int c, int tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int o = c * (BN_HP * 32) + tfrag + (ky * 10 + kx) * 32 + ((lg ^ (((prow + ky) & 1) << 1)) << 3);
-        h8 xh[4], xl[4];
+        h8 xh[4], xl[4], bs[CT1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xh[i] = *(const h8*)(Th + o + i * 640); xl[i] = *(const h8*)(Tl + o + i * 640); }
-        const h8 bs0 = scale_m11(F[0][0]), bs1 = scale_m11(F[1][0]);
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) bs[j] = scale_m11(F.f[j][0]);
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc2[i][0] = mfma16(term == 0 ? F[0][0] : term == 1 ? F[0][1] : bs0, term == 2 ? xl[i] : xh[i], acc2[i][0]);
-                acc2[i][1] = mfma16(term == 0 ? F[1][0] : term == 1 ? F[1][1] : bs1, term == 2 ? xl[i] : xh[i], acc2[i][1]);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CT1; ++j)
+                    acc2[i][j] = mfma16(term == 0 ? F.f[j][0] : term == 1 ? F.f[j][1] : bs[j], term == 2 ? xl[i] : xh[i], acc2[i][j]);
     };
-    // 36 (chunk, tap) steps, chunk-major; weights two steps ahead in a ring of three fragment sets.
-    // The weight slab of step s = c * 9 + tap is tap * 4 + c.
-    for (int c = 0; c < 4; ++c) {
+    // NCH * 9 (chunk, tap) steps, chunk-major; weights two steps ahead in a ring of three fragment sets.
+    // The weight slab of step s = c * 9 + tap is tap * NCH + c.
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap += 3) {
             const int s2 = c * 9 + tap + 2;                     // steps s2, s2+1, s2+2 are fetched in this round
-            auto slab_of = [](int s) { const int cc = s / 9; return (s - cc * 9) * 4 + cc; };
-            load_w(w2, k.w2, slab_of(s2), 4, wave);
+            auto slab_of = [](int s) { const int cc = s / 9; return (s - cc * 9) * NCH + cc; };
+            load_w(w2, k.w2, slab_of(s2), NCH, wave * CT1);
             compute2(w0, c, tap);
-            if (s2 + 1 < 36) load_w(w0, k.w2, slab_of(s2 + 1), 4, wave);
+            if (s2 + 1 < NCH * 9) load_w(w0, k.w2, slab_of(s2 + 1), NCH, wave * CT1);
             compute2(w1, c, tap + 1);
-            if (s2 + 2 < 36) load_w(w1, k.w2, slab_of(s2 + 2), 4, wave);
+            if (s2 + 2 < NCH * 9) load_w(w1, k.w2, slab_of(s2 + 2), NCH, wave * CT1);
             compute2(w2, c, tap + 2);
         }
     }
     __syncthreads();                                            // T is dead: U may overwrite it
 
     // conv3's first weights, then conv2's result into U
-    WFrag v0[2], v1[2];
-    load_w(v0[0], k.w3, 0, 8, 2 * wave);
-    load_w(v0[1], k.w3, 0, 8, 2 * wave + 1);
+    WFrag<CT3> v0, v1;
+    load_w(v0, k.w3, 0, 2 * NCH, wave * CT3);
     {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int n0 = wave * 32 + ct * 16 + lg * 4;
+        for (int j = 0; j < CT1; ++j) {
+            const int gct = wave * CT1 + j;
+            const int n0 = gct * 16 + lg * 4;
             const f32x4 bias = *(const f32x4*)(k.b2 + n0), wsc = *(const f32x4*)(k.s2 + n0);
-            const int g = ct * 2 + (lg >> 1);
+            const int g = (gct & 1) * 2 + (lg >> 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc2[i][ct][r], wsc[r], bias[r]), 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc2[i][j][r], wsc[r], bias[r]), 0.f);
                 h4 hi, lo;
                 split4(v, ninf, hi, lo, amax);
-                const int o = (wave * 64 + i * 16 + lp) * 32 + ((g ^ (((lp >> 2) & 1) << 1)) << 3) + sub;
+                const int o = ((gct >> 1) * 64 + i * 16 + lp) * 32 + ((g ^ (((lp >> 2) & 1) << 1)) << 3) + sub;
                 *(h4*)(Uh + o) = hi;
                 *(h4*)(Ul + o) = lo;
             }
@@ -265,41 +278,32 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     }
     __syncthreads();
 
-    // ------------------------------------------------------------------ conv3: 1x1 128 -> 256, this wave's 64 channels
-    f32x4 acc3[4][4];
+    // ------------------------------------------------------------------ conv3: 1x1 P -> 2 P, this wave's P / 2 channels
+    f32x4 acc3[4][CT3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute3 = [&](const WFrag (&F)[2], int c) {
+        for (int j = 0; j < CT3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute3 = [&](const WFrag<CT3>& F, int c) {
         h8 xh[4], xl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xh[i] = *(const h8*)(Uh + c * 2048 + i * 512 + sfrag); xl[i] = *(const h8*)(Ul + c * 2048 + i * 512 + sfrag); }
-        h8 bs[2][2];
+        h8 bs[CT3];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) bs[j][ct] = scale_m11(F[j][ct][0]);
+        for (int j = 0; j < CT3; ++j) bs[j] = scale_m11(F.f[j][0]);
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc3[i][2 * j + ct] = mfma16(term == 0 ? F[j][ct][0] : term == 1 ? F[j][ct][1] : bs[j][ct],
-                                                     term == 2 ? xl[i] : xh[i], acc3[i][2 * j + ct]);
+                for (int j = 0; j < CT3; ++j)
+                    acc3[i][j] = mfma16(term == 0 ? F.f[j][0] : term == 1 ? F.f[j][1] : bs[j], term == 2 ? xl[i] : xh[i], acc3[i][j]);
     };
 #pragma unroll
-    for (int c = 0; c < 4; c += 2) {
-        load_w(v1[0], k.w3, c + 1, 8, 2 * wave);
-        load_w(v1[1], k.w3, c + 1, 8, 2 * wave + 1);
+    for (int c = 0; c < NCH; c += 2) {
+        load_w(v1, k.w3, c + 1, 2 * NCH, wave * CT3);
         compute3(v0, c);
-        if (c + 2 < 4) {
-            load_w(v0[0], k.w3, c + 2, 8, 2 * wave);
-            load_w(v0[1], k.w3, c + 2, 8, 2 * wave + 1);
-        }
+        if (c + 2 < NCH) load_w(v0, k.w3, c + 2, 2 * NCH, wave * CT3);
         compute3(v1, c + 1);
     }
 
@@ -313,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
         const float* rp = k.res + (long)b * k.rsn + (long)oy * k.rsh + (long)ox * k.rsw;
         float* dp = k.dst + (long)b * k.dsn + (long)oy * k.dsh + (long)ox * k.dsw;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n0 = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + lg * 4;
+        for (int j = 0; j < CT3; ++j) {
+            const int n0 = (wave * CT3 + j) * 16 + lg * 4;
             const f32x4 bias = *(const f32x4*)(k.b3 + n0), wsc = *(const f32x4*)(k.s3 + n0);
             const f32x4 r = *(const f32x4*)(rp + n0);
             f32x4 v;
@@ -333,10 +337,11 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     FUSG_CHECK(d != nullptr, "hg_bottleneck: null descriptor");
     const fusg_tensor& x = d->x;
-    FUSG_CHECK(d->planes == BN_P, "hg_bottleneck: planes %d (only 128 is built)", d->planes);
+    const int P = d->planes;
+    FUSG_CHECK(P == 128 || P == 64, "hg_bottleneck: planes %d (64 and 128 are built)", d->planes);
     FUSG_CHECK(is_nhwc(x) && x.c % 32 == 0 && x.c >= 32 && x.c <= 4096, "hg_bottleneck: x must be NHWC-physical f32 with c %% 32 == 0");
-    FUSG_CHECK(is_nhwc(d->res) && is_nhwc(d->dst) && same_nhw(x, d->res) && same_nhw(x, d->dst) && d->res.c == 2 * BN_P &&
-               d->dst.c == 2 * BN_P, "hg_bottleneck: res / dst must be NHWC-physical f32 [n, 256, h, w] like x");
+    FUSG_CHECK(is_nhwc(d->res) && is_nhwc(d->dst) && same_nhw(x, d->res) && same_nhw(x, d->dst) && d->res.c == 2 * P &&
+               d->dst.c == 2 * P, "hg_bottleneck: res / dst must be NHWC-physical f32 [n, 2 * planes, h, w] like x");
     FUSG_CHECK(x.data != d->dst.data && d->res.data != d->dst.data, "hg_bottleneck: dst must not alias x or res (neighbouring patches read x's halo)");
     const void* ptrs[] = {d->pre_scale, d->pre_shift, d->w1frag, d->bias1, d->wscale1, d->w2frag, d->bias2, d->wscale2,
                           d->w3frag, d->bias3, d->wscale3};
@@ -360,12 +365,13 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     k.tiles_x = (k.W + 7) / 8; k.tiles_y = (k.H + 7) / 8;
     const long wgs = (long)k.B * k.tiles_x * k.tiles_y;
     FUSG_CHECK(wgs < (1L << 31), "hg_bottleneck: grid");
-    const void* fn = (const void*)hg_bneck_h3;
-    if (hipError_t e = ensure_dyn_lds(fn, (int)BN_LDS); e != hipSuccess) { set_error("hg_bottleneck: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
+    const void* fn = P == 128 ? (const void*)hg_bneck_h3<128> : (const void*)hg_bneck_h3<64>;
+    const size_t lds = bneck_lds(P);
+    if (hipError_t e = ensure_dyn_lds(fn, (int)lds); e != hipSuccess) { set_error("hg_bottleneck: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
     const double M = (double)x.n * x.h * x.w;
-    prof_begin(0, s, 2.0 * M * ((double)x.c * BN_P + 9.0 * BN_P * BN_P + 2.0 * BN_P * BN_P));   // the three convs' own FLOPs (no halo recompute)
+    prof_begin(0, s, 2.0 * M * ((double)x.c * P + 9.0 * P * P + 2.0 * P * P));   // the three convs' own FLOPs (no halo recompute)
     void* args[] = {(void*)&k};
-    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)wgs), dim3(256), args, BN_LDS, s);
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)wgs), dim3(256), args, lds, s);
     prof_end(0, s);
     if (e != hipSuccess) { set_error("hg_bottleneck launch: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
     note_conv_kernel(FUSG_CONV_BNECK);

@@ -396,12 +396,12 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
 
 def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> bool:
     """Can this hourglass Bottleneck (packed plans c1, c2, c3 + bn1 affine) run as ONE launch (fusg_hg_bottleneck)?
-    planes 128, split-fp16 arithmetic, channels of x a multiple of 32.  FUSG_NO_BNECK=1 keeps the three launches;
+    planes 64 or 128, split-fp16 arithmetic, channels of x a multiple of 32.  FUSG_NO_BNECK=1 keeps the three launches;
     FUSG_BNECK_MAXHW=n fuses only levels of at most n x n pixels."""
     if (precision or PRECISION) != "f16x3" or _env_set("FUSG_NO_BNECK"):
         return False
     c1, c2, c3 = p["c1"], p["c2"], p["c3"]
-    if not (c1.cout == 128 and c2.cout == 128 and c3.cout == 256 and c1.kh == 1 and c2.kh == 3 and c3.kh == 1
+    if not (c1.cout in (64, 128) and c2.cout == c1.cout and c3.cout == 2 * c1.cout and c1.kh == 1 and c2.kh == 3 and c3.kh == 1
             and c1.c0k == x.shape[1] and x.shape[1] % 32 == 0 and c1.c1k == 0 and c2.pad == 1 and c2.stride == 1):
         return False
     lim = _os.environ.get("FUSG_BNECK_MAXHW")
@@ -414,7 +414,8 @@ def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> 
     `res` defaults to x (no downsample conv)."""
     res = x if res is None else res
     b, _, h, w = x.shape
-    out = nhwc_empty(b, 256, h, w, x.device)
+    planes = p["c1"].cout
+    out = nhwc_empty(b, 2 * planes, h, w, x.device)
     d = L.BneckDesc()
     d.x, d.res, d.dst = desc(x), desc(res), desc(out)
     d.pre_scale, d.pre_shift = p["pre"][0].data_ptr(), p["pre"][1].data_ptr()
@@ -425,7 +426,7 @@ def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> 
         setattr(d, "bias%d" % i, dev["bias"].data_ptr())
         setattr(d, "wscale%d" % i, dev["wscale"].data_ptr())
     d.status = status_word(x.device).data_ptr()
-    d.planes = 128
+    d.planes = planes
     L.check(L.lib().fusg_hg_bottleneck(C.byref(d), stream_ptr()), "hg_bottleneck")
     return out
 

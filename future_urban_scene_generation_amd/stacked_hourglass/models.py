@@ -12,7 +12,7 @@ Execution is a flat sequence of libfusg launches over NHWC activations:
   * residual adds (``out += residual``, ``x + fc_ + score_``) are conv epilogues;
   * max-pool and ``up1 + upsample(low3)`` are single HBM-bound kernels.
 A Bottleneck is therefore 3 launches (4 with a downsample conv) instead of 10 framework ops - and, on the
-split-fp16 path, ONE launch for every block with 128 planes (fusg_hg_bottleneck: both intermediates stay in LDS).
+split-fp16 path, ONE launch per block (fusg_hg_bottleneck, 64 or 128 planes: both intermediates stay in LDS).
 """
 from __future__ import annotations
 
@@ -139,7 +139,7 @@ class HourglassNet(FusedNet):
     # ------------------------------------------------------------------ execution
     @staticmethod
     def _bottleneck(p: dict, x: torch.Tensor) -> torch.Tensor:
-        if ops.bottleneck_ok(p, x):                  # planes 128, f16x3: the whole block in one launch
+        if ops.bottleneck_ok(p, x):                  # f16x3: the whole block in one launch
             return ops.bottleneck(p, x, None if p["ds"] is None else ops.conv(p["ds"], x))
         t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU)
         t = ops.conv(p["c2"], t, act=L.ACT_RELU)

@@ -214,8 +214,8 @@ int64_t fusg_conv2d_plan(fusg_conv_desc* d);
  *   out = res + conv3_1x1( relu(bn3( conv2_3x3( relu(bn2( conv1_1x1( relu(bn1(x)) ))) ))) )
  * (stacked_hourglass/models.py:22-42; bn2 / bn3 are folded into conv1 / conv2 at pack time, bn1 is the per-channel
  * affine `pre_scale`, `pre_shift`; `res` is x itself or the block's 1x1 `downsample` conv of x, models.py:37-38).
- * planes must be 128 (every Bottleneck of the hourglass levels, `layer2`, `layer3` and `res`: conv1 Cin -> 128,
- * conv2 128 -> 128, conv3 128 -> 256); x has Cin % 32 == 0 channels, res and dst 256.
+ * planes P is 128 (every Bottleneck of the hourglass levels, `layer2`, `layer3` and `res`) or 64 (`layer1`): conv1
+ * Cin -> P, conv2 P -> P, conv3 P -> 2 P; x has Cin % 32 == 0 channels, res and dst 2 P.
  * A workgroup owns an 8 x 8 pixel patch: conv1 is evaluated on the patch's 10 x 10 halo (zero outside the image, as
  * conv2's zero padding requires), its output and conv2's never leave LDS (already split into fp16 pairs), so the
  * block reads x and res once and writes out once - the three launches it replaces move 2.2x the bytes and, on the
@@ -229,11 +229,11 @@ typedef struct fusg_bneck_desc {
     fusg_tensor x, res, dst;
     const float* pre_scale;      /* [Cin] bn1 as y = x * scale + shift, then ReLU               */
     const float* pre_shift;
-    const void*  w1frag; const float* bias1; const float* wscale1;     /* conv1 (+bn2): Cin -> 128, 1x1  */
-    const void*  w2frag; const float* bias2; const float* wscale2;     /* conv2 (+bn3): 128 -> 128, 3x3  */
-    const void*  w3frag; const float* bias3; const float* wscale3;     /* conv3: 128 -> 256, 1x1         */
+    const void*  w1frag; const float* bias1; const float* wscale1;     /* conv1 (+bn2): Cin -> P, 1x1    */
+    const void*  w2frag; const float* bias2; const float* wscale2;     /* conv2 (+bn3): P -> P, 3x3      */
+    const void*  w3frag; const float* bias3; const float* wscale3;     /* conv3: P -> 2 P, 1x1           */
     int32_t*     status;
-    int32_t      planes;         /* 128 */
+    int32_t      planes;         /* P: 64 or 128 */
     int32_t      _pad;
 } fusg_bneck_desc;
 int fusg_hg_bottleneck(const fusg_bneck_desc* d, void* stream);

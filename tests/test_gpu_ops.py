@@ -570,14 +570,15 @@ def test_splitk_in_launch_combine_equals_reduce_kernel(precision, monkeypatch):
 
 
 # ---- fused hourglass Bottleneck (fusg_hg_bottleneck) -----------------------------------------------------------------
-def _bneck_params(cin, seed=0, scale=1.0):
-    """A pre-activation Bottleneck with 128 planes as the hourglass packs it: bn1 affine, conv1 + bn2, conv2 + bn3, conv3."""
+def _bneck_params(cin, seed=0, scale=1.0, planes=128):
+    """A pre-activation Bottleneck as the hourglass packs it: bn1 affine, conv1 + bn2, conv2 + bn3, conv3."""
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)                                                       # noqa: E731
+    P = planes
     s1, h1 = torch.rand(cin, generator=g) + 0.5, rn(cin) * 0.2
-    w1, b1 = rn(128, cin, 1, 1) * scale / cin ** 0.5, rn(128) * 0.1
-    w2, b2 = rn(128, 128, 3, 3) * scale / 1152 ** 0.5, rn(128) * 0.1
-    w3, b3 = rn(256, 128, 1, 1) * scale / 128 ** 0.5, rn(256) * 0.1
+    w1, b1 = rn(P, cin, 1, 1) * scale / cin ** 0.5, rn(P) * 0.1
+    w2, b2 = rn(P, P, 3, 3) * scale / (9 * P) ** 0.5, rn(P) * 0.1
+    w3, b3 = rn(2 * P, P, 1, 1) * scale / P ** 0.5, rn(2 * P) * 0.1
     p = {"pre": (s1.to(dev()), h1.to(dev())), "c1": pack.pack_conv(w1, b1).to(dev()),
          "c2": pack.pack_conv(w2, b2, pad=1).to(dev()), "c3": pack.pack_conv(w3, b3).to(dev()), "ds": None}
     return p, (s1, h1, w1, b1, w2, b2, w3, b3)
@@ -597,20 +598,22 @@ def _bneck_unfused(p, x, res):
     return ops.conv(p["c3"], t, res0=res, precision="f16x3")
 
 
-@pytest.mark.parametrize("B,cin,H,W,own_res", [(2, 256, 8, 8, False), (3, 256, 4, 4, False), (2, 256, 16, 16, False),
-                                                 (1, 256, 64, 64, False), (2, 128, 32, 32, True), (1, 256, 12, 20, False),
-                                                 (2, 64, 5, 9, True)])
-def test_hg_bottleneck_fused(B, cin, H, W, own_res, precision):
+@pytest.mark.parametrize("B,cin,H,W,own_res,planes", [(2, 256, 8, 8, False, 128), (3, 256, 4, 4, False, 128),
+                                                        (2, 256, 16, 16, False, 128), (1, 256, 64, 64, False, 128),
+                                                        (2, 128, 32, 32, True, 128), (1, 256, 12, 20, False, 128),
+                                                        (2, 64, 5, 9, True, 128), (2, 64, 32, 32, True, 64),
+                                                        (1, 128, 16, 24, False, 64), (1, 64, 128, 128, True, 64)])
+def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision):
     """One-launch Bottleneck against an fp64 reference and against the three launches it replaces (same arithmetic,
     different summation order): error relative to the output's largest magnitude <= 2e-6 (observed ~3e-7), and no
     worse than 2x the three-launch path's."""
     if precision != "f16x3":
         pytest.skip("the fused block exists on the split-fp16 path only")
     from conftest import record
-    p, prm = _bneck_params(cin, seed=21)
+    p, prm = _bneck_params(cin, seed=21, planes=planes)
     x = _rand(B, cin, H, W, seed=22)
-    res = _rand(B, 256, H, W, seed=23) if own_res else x
-    assert own_res or cin == 256
+    res = _rand(B, 2 * planes, H, W, seed=23) if own_res else x
+    assert own_res or cin == 2 * planes
     ref = _bneck_ref(x, res, prm)
     xin = _nhwc(x)
     rin = _nhwc(res) if own_res else xin
@@ -662,9 +665,10 @@ def test_hg_bottleneck_fused_random_shapes(precision):
     for it in range(16):
         cin = int(rng.choice([32, 64, 128, 256, 288]))
         B, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
-        p, _ = _bneck_params(cin, seed=100 + it)
+        planes = int(rng.choice([64, 128]))
+        p, _ = _bneck_params(cin, seed=100 + it, planes=planes)
         x = _rand(B, cin, H, W, seed=200 + it)
-        res = _rand(B, 256, H, W, seed=300 + it)
+        res = _rand(B, 2 * planes, H, W, seed=300 + it)
         xin, rin = _nhwc(x), _nhwc(res)
         got = ops.bottleneck(p, xin, rin)
         un = _bneck_unfused(p, xin, rin)

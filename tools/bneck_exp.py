@@ -47,6 +47,25 @@ def main():
         t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision="f16x3")
         return ops.conv(p["c3"], t, res0=x, precision="f16x3")
 
+    # the `layer1` block: 64 planes at 128 x 128 (its residual is the block's downsample conv: a separate launch either way)
+    g2 = torch.Generator().manual_seed(1)
+    rn2 = lambda *s: torch.randn(*s, generator=g2)                                                     # noqa: E731
+    p64 = {"pre": ((torch.rand(64, generator=g2) + 0.5).to(dev), (rn2(64) * 0.2).to(dev)),
+           "c1": pack.pack_conv(rn2(64, 64, 1, 1) / 8.0, rn2(64) * 0.1).to(dev),
+           "c2": pack.pack_conv(rn2(64, 64, 3, 3) / 24.0, rn2(64) * 0.1, pad=1).to(dev),
+           "c3": pack.pack_conv(rn2(128, 64, 1, 1) / 8.0, rn2(128) * 0.1).to(dev), "ds": None}
+    x = ops.as_nhwc(rn2(B, 64, 128, 128).to(dev))
+    r = ops.as_nhwc(rn2(B, 128, 128, 128).to(dev))
+
+    def unfused64():
+        t = ops.conv(p64["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p64["pre"], act=L.ACT_RELU, precision="f16x3")
+        t = ops.conv(p64["c2"], t, act=L.ACT_RELU, precision="f16x3")
+        return ops.conv(p64["c3"], t, res0=r, precision="f16x3")
+
+    fl = 2.0 * B * 128 * 128 * (64 * 64 + 576 * 64 + 64 * 128)
+    a, b = timed(lambda: ops.bottleneck(p64, x, r)), timed(unfused64)
+    print(f"B={B} 128x128 planes 64: fused {a * 1e3:8.1f} us {fl / a / 1e9:6.1f} TF | 3 launches {b * 1e3:8.1f} us {fl / b / 1e9:6.1f} TF | x{b / a:.2f}", flush=True)
+    del x, r
     for hw in (128, 64, 32, 16, 8, 4):
         if hw == 128 and B > 8:
             continue
