@@ -60,8 +60,9 @@ def main():
         e1.synchronize()
         b, c, h, w = x.shape
         m = b * h * w
-        rows.append((net[0], f"bottleneck {c}->128->128->256 fused", f"{h}x{w}", m, c + 1152 + 128, e0.elapsed_time(e1),
-                     2.0 * m * (c * 128 + 1152 * 128 + 128 * 256)))
+        pl = p["c1"].cout
+        rows.append((net[0], f"bottleneck {c}->{pl}->{pl}->{2 * pl} fused", f"{h}x{w}", m, c + 10 * pl, e0.elapsed_time(e1),
+                     2.0 * m * (c * pl + 9 * pl * pl + 2 * pl * pl)))
         return out
 
     ops.bottleneck = timed_b
