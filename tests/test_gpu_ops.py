@@ -675,3 +675,21 @@ def test_hg_bottleneck_fused_random_shapes(precision):
         err = float((got - un).abs().max() / un.abs().max())
         assert err < 1e-6, (cin, B, H, W, err)
     assert not ops.range_exceeded(dev())
+
+
+def test_hg_bottleneck_fused_is_deterministic(precision):
+    """Race check of the fused block's LDS hand-offs (conv1 -> T -> conv2 -> U -> conv3, T and U overlaid): 100 launches
+    on a grid that fills the chip several times over, interleaved with a kernel that dirties LDS-sized state, must give
+    bit-identical outputs."""
+    if precision != "f16x3":
+        pytest.skip("split-fp16 path only")
+    for planes, cin, hw in ((128, 256, 64), (64, 64, 96)):
+        p, _ = _bneck_params(cin, seed=41, planes=planes)
+        x = _nhwc(_rand(8, cin, hw, hw, seed=42))
+        r = _nhwc(_rand(8, 2 * planes, hw, hw, seed=43))
+        first = ops.bottleneck(p, x, r).clone()
+        for it in range(100):
+            if it % 10 == 0:
+                _bneck_unfused(p, x, r)                      # other kernels in between (different LDS contents)
+            got = ops.bottleneck(p, x, r)
+            assert torch.equal(got, first), (planes, it)
