@@ -14,7 +14,7 @@ def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
     # a stand-in for the reference checkout: only the sibling modules the merged packages must keep finding
     ref = tmp_path / "reference"
     for pkg, mod in (("warp_learn", "planes_utils"), ("warp_learn", "online_visibility"), ("edgeconnect", "config"),
-                     ("edgeconnect", "utils")):
+                     ("edgeconnect", "utils"), ("utils", "crop_utils"), ("utils", "geometry")):
         d = ref / pkg
         d.mkdir(parents=True, exist_ok=True)
         (d / "__init__.py").write_text("")
@@ -31,6 +31,8 @@ def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
         from edgeconnect.networks import InpaintGenerator, EdgeGenerator, Discriminator   # edgeconnect/models.py:5
         import warp_learn.planes_utils, warp_learn.online_visibility, edgeconnect.config, edgeconnect.utils
         import vunet.data_utils
+        from utils.pnp_utils import cpc_rodr_4_angles                          # trajectory_inference.py:25
+        import utils.crop_utils, utils.geometry
         from future_urban_scene_generation_amd.pipeline import load_schema
         from future_urban_scene_generation_amd.synth import schema_of
         nets = {"hg": HourglassNet(num_stacks=2, num_blocks=1, num_classes=12), "icn": G_Resnet(21),
@@ -40,6 +42,7 @@ def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
                "schema_ok": {k: list(schema_of(v.state_dict()).items()) == list(load_schema(k).items()) for k, v in nets.items()},
                "siblings": [warp_learn.planes_utils.MARKER, warp_learn.online_visibility.MARKER, edgeconnect.config.MARKER,
                             edgeconnect.utils.MARKER, vunet.data_utils.MARKER],
+               "pnp": cpc_rodr_4_angles.__module__, "utils_siblings": [utils.crop_utils.MARKER, utils.geometry.MARKER],
                "to_str": str(next(nets["hg"].to("cpu").parameters()).device)}
         print("RESULT " + json.dumps(out))
     """)
@@ -50,5 +53,7 @@ def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert all(m.startswith("future_urban_scene_generation_amd.") for m in out["modules"].values()), out["modules"]
     assert all(out["schema_ok"].values()), out["schema_ok"]
+    assert out["pnp"] == "future_urban_scene_generation_amd.utils.pnp_utils"
+    assert out["utils_siblings"] == ["reference utils.crop_utils", "reference utils.geometry"]
     assert out["siblings"] == ["reference warp_learn.planes_utils", "reference warp_learn.online_visibility",
                                "reference edgeconnect.config", "reference edgeconnect.utils", "reference vunet.data_utils"]
