@@ -171,6 +171,53 @@ class PlanRecorder:
                                           src_ring.stride(0) * src_ring.element_size(), stream_ptr()), "plan_add_h2d")
 
 
+# ---- side streams ---------------------------------------------------------------------------------------------------
+# Launches that depend on little else (the VUnet's shape encoder, its 1x1 skip projections, the conditioning of its
+# autoregressive blocks) are issued on side streams so that they do not lengthen the chain of dependent launches on
+# the main one - what bounds a pass at small batches.  Both directions of every hand-over are explicit
+# (fork_to / join_from; through the plan recorder while a pass is being recorded), and a tensor that a side stream
+# reads must be kept referenced by the caller until the join: the caching allocator only knows the stream a tensor was
+# allocated on, and a recorded pass replays the addresses of the recording with no allocator in the loop.
+# Keep the number of streams of a pass at FOUR (caller's + VUnet + hourglass + VUnet shape encoder): HIP maps streams
+# onto 4 hardware queues by default, and a fifth / sixth stream (tried: the VUnet's 14 skip projections and its AR-block
+# conditioning on their own streams) shares a queue with another one - measured 3x SLOWER at every batch size
+# (B=1 replay 2.2 -> 7.1 ms, B=32 1398 -> 1281 crops/s).
+_SIDE = {}
+
+
+def side_streams_enabled() -> bool:
+    return _os.environ.get("FUSG_STREAMS", "1") != "0" and _os.environ.get("FUSG_VUNET_SPLIT", "1") != "0"
+
+
+def side_stream(name: str, device) -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    key = (name, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
+
+def fork_to(st: "torch.cuda.Stream") -> None:
+    """`st` may not start anything issued from now on before what is queued on the current stream has finished."""
+    cur = torch.cuda.current_stream(st.device)
+    if RECORDER is None:
+        st.wait_stream(cur)
+    else:
+        RECORDER.dependency(st.cuda_stream, cur.cuda_stream)
+
+
+def join_from(st: "torch.cuda.Stream", tensors=()) -> None:
+    """The current stream waits for `st`; `tensors` (allocated under `st`) will be used on the current stream."""
+    cur = torch.cuda.current_stream(st.device)
+    if RECORDER is None:
+        cur.wait_stream(st)
+    else:
+        RECORDER.dependency(cur.cuda_stream, st.cuda_stream)
+    for t in tensors:
+        t.record_stream(cur)
+
+
 def desc(t: Optional[torch.Tensor]) -> L.Tensor:
     """fusg_tensor for a 4-D torch tensor (or an absent tensor: a shared all-zero struct, never written to)."""
     if t is None:

@@ -195,19 +195,10 @@ class VehiclePipeline:
         on the appearance half (forward_enc_up -> forward_enc_down), so the VUnet's chain of dependent launches - the
         longest of the pass - is a third shorter.  FUSG_VUNET_SPLIT=0 (or FUSG_STREAMS=0) keeps one stream."""
         from . import ops
-        if (os.environ.get("FUSG_STREAMS", "1") == "0" or os.environ.get("FUSG_VUNET_SPLIT", "1") == "0"
-                or self.device.type != "cuda"):
+        if not ops.side_streams_enabled() or self.device.type != "cuda":
             return fn(), (lambda: None)
-        cur = torch.cuda.current_stream(self.device)
-        pool = self.__dict__.setdefault("_streams", {})
-        st = pool.get(name)
-        if st is None:
-            st = pool[name] = torch.cuda.Stream(device=self.device, priority=-1)
-        rec = ops.RECORDER
-        if rec is None:
-            st.wait_stream(cur)
-        else:
-            rec.dependency(st.cuda_stream, cur.cuda_stream)
+        st = ops.side_stream(name, self.device)
+        ops.fork_to(st)
         with torch.cuda.stream(st):
             res = fn()
 
@@ -218,15 +209,7 @@ class VehiclePipeline:
                 for q in o:
                     yield from tensors(q)
 
-        def join():
-            if rec is None:
-                cur.wait_stream(st)
-            else:
-                rec.dependency(cur.cuda_stream, st.cuda_stream)
-            for t in tensors(res):
-                t.record_stream(cur)
-
-        return res, join
+        return res, (lambda: ops.join_from(st, list(tensors(res))))
 
     def compile(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> "CompiledPass":
         """Record one crop pass for inputs of `batch`'s shapes into a fusg_plan and return the object that replays it:
