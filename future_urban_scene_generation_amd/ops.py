@@ -178,10 +178,9 @@ class PlanRecorder:
 # (fork_to / join_from; through the plan recorder while a pass is being recorded), and a tensor that a side stream
 # reads must be kept referenced by the caller until the join: the caching allocator only knows the stream a tensor was
 # allocated on, and a recorded pass replays the addresses of the recording with no allocator in the loop.
-# Keep the number of streams of a pass at FOUR (caller's + VUnet + hourglass + VUnet shape encoder): HIP maps streams
-# onto 4 hardware queues by default, and a fifth / sixth stream (tried: the VUnet's 14 skip projections and its AR-block
-# conditioning on their own streams) shares a queue with another one - measured 3x SLOWER at every batch size
-# (B=1 replay 2.2 -> 7.1 ms, B=32 1398 -> 1281 crops/s).
+# Fork each branch ONCE and join it once: every additional event hand-over between streams costs ~0.2 ms of latency
+# on this stack (measured: the VUnet's 14 skip projections forked level by level onto a fifth stream made a B=1 replay
+# 2.2 -> 4.1 ms and B=8 1223 -> 966 crops/s; GPU_MAX_HW_QUEUES made no difference) - DESIGN.md §9.
 _SIDE = {}
 
 
