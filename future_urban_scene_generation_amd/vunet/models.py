@@ -172,6 +172,12 @@ class Vunet_fix_res(FusedNet):
             r = parents.get(name)
             if r is not None and r.c_in != r.c_out:
                 split = (r.c_out, r.c_in - r.c_out)
+            if name == "shape_decoder_6.conv" and w.shape[0] * w.shape[3] <= 32 and split is None and m.stride == 1:
+                # the 3x3 -> 3 channel head at full resolution: 3x1 implicit GEMM with 9 columns + horizontal gather-sum
+                # (a third of the matrix work of the 32-column-padded 3x3, and the NCHW result is written by a
+                # streaming kernel instead of 4-byte scattered epilogue stores)
+                P[name] = pack.pack_conv_rowsplit(w, h.bias, pad=m.padding).to(device)
+                continue
             P[name] = pack.pack_conv(w, h.bias, c_split=split, stride=m.stride, pad=m.padding).to(device)
         return P
 
@@ -394,7 +400,8 @@ class Vunet_fix_res(FusedNet):
         skip_b = ops.as_nhwc(skips.pop())
         x = self._residual("shape_decoder_6.residual_0", x, skip_a)
         x = self._residual("shape_decoder_6.residual_1", x, skip_b)
-        x = ops.conv(P["shape_decoder_6.conv"], x, nchw_out=True)
+        head = P["shape_decoder_6.conv"]
+        x = ops.conv_rowsplit(head, x, nchw_out=True) if head.rowsplit is not None else ops.conv(head, x, nchw_out=True)
         assert not skips
         return x, mu, z
 
