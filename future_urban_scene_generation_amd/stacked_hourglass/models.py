@@ -134,6 +134,12 @@ class HourglassNet(FusedNet):
             if i < self.num_stacks - 1:
                 P["fc_"].append(pack.pack_conv(self.fc_[i].weight, self.fc_[i].bias).to(device))
                 P["score_"].append(pack.pack_conv(self.score_[i].weight, self.score_[i].bias).to(device))
+                # x + fc_(y) + score_(score) (models.py:164-166) as ONE two-source 1x1 convolution of cat[y, score] with
+                # the residual x: the score map's 12 channels are zero-padded to a 32-channel source (halo kernel)
+                wj = torch.cat([self.fc_[i].weight.detach().float().cpu(), self.score_[i].weight.detach().float().cpu()], dim=1)
+                bj = self.fc_[i].bias.detach().float().cpu() + self.score_[i].bias.detach().float().cpu()
+                P.setdefault("join", []).append(pack.pack_conv(wj, bj, c_split=(wj.shape[1] - self.num_classes, self.num_classes),
+                                                               cin_pad=32).to(device))
         return P
 
     # ------------------------------------------------------------------ execution
@@ -181,9 +187,16 @@ class HourglassNet(FusedNet):
             y = self._hourglass(P["hg"][i], 4, x)
             y = self._seq(P["res"][i], y)
             y = ops.conv(P["fc"][i], y, act=L.ACT_RELU)
-            score = ops.conv(P["score"][i], y)
+            last = i == self.num_stacks - 1
+            joined = not last and ops.halo_precision() and y.shape[1] % 32 == 0 and self.num_classes <= 32
+            b, _, h, w = y.shape
+            # (for the joined form the score map lives in a zero-filled 32-channel buffer: a source of the next launch)
+            score = ops.conv(P["score"][i], y, out=ops.nhwc_empty(b, 32, h, w, y.device, zero=True)[:, :self.num_classes]) \
+                if joined else ops.conv(P["score"][i], y)
             heatmaps.append(ops.to_nchw(score))
-            if i < self.num_stacks - 1:
+            if joined:
+                x = ops.conv(P["join"][i], y, score, res0=x)
+            elif not last:
                 t = ops.conv(P["fc_"][i], y, res0=x)
                 x = ops.conv(P["score_"][i], score, res0=t)
         return {"heatmaps": heatmaps}
