@@ -140,6 +140,13 @@ class HourglassNet(FusedNet):
                 bj = self.fc_[i].bias.detach().float().cpu() + self.score_[i].bias.detach().float().cpu()
                 P.setdefault("join", []).append(pack.pack_conv(wj, bj, c_split=(wj.shape[1] - self.num_classes, self.num_classes),
                                                                cin_pad=32).to(device))
+                # ... and the score conv with its output channels zero-padded to 32, so that the launch itself writes the
+                # padding every pass (a recorded pass replays addresses: a memset at record time would not be replayed)
+                ws = torch.zeros(32, self.score[i].weight.shape[1], 1, 1)
+                bs = torch.zeros(32)
+                ws[:self.num_classes] = self.score[i].weight.detach().float().cpu()
+                bs[:self.num_classes] = self.score[i].bias.detach().float().cpu()
+                P.setdefault("score32", []).append(pack.pack_conv(ws, bs).to(device))
         return P
 
     # ------------------------------------------------------------------ execution
@@ -189,10 +196,9 @@ class HourglassNet(FusedNet):
             y = ops.conv(P["fc"][i], y, act=L.ACT_RELU)
             last = i == self.num_stacks - 1
             joined = not last and ops.halo_precision() and y.shape[1] % 32 == 0 and self.num_classes <= 32
-            b, _, h, w = y.shape
-            # (for the joined form the score map lives in a zero-filled 32-channel buffer: a source of the next launch)
-            score = ops.conv(P["score"][i], y, out=ops.nhwc_empty(b, 32, h, w, y.device, zero=True)[:, :self.num_classes]) \
-                if joined else ops.conv(P["score"][i], y)
+            # (for the joined form the score map is the first num_classes channels of a 32-channel launch whose other
+            # channels are exact zeros: a 32-channel source of the next launch)
+            score = ops.conv(P["score32"][i], y)[:, :self.num_classes] if joined else ops.conv(P["score"][i], y)
             heatmaps.append(ops.to_nchw(score))
             if joined:
                 x = ops.conv(P["join"][i], y, score, res0=x)
