@@ -12,6 +12,7 @@ echo "bench cfg1 (both precision legs) done"
 timeout -k 10 500 python bench.py --inpaint --no-cpu-baseline > $out/bench_cfg2.log 2>&1 && grep '^{"metric"' $out/bench_cfg2.log > $out/${tag}_bench_cfg2_inpaint.json
 echo "bench cfg2 done"
 timeout -k 10 500 python bench.py --res 512 --batch 16 --precision f16x3 --no-cpu-baseline --no-clip > $out/bench_512.log 2>&1 && grep '^{"metric"' $out/bench_512.log > $out/${tag}_bench_512_b16_f16x3.json
+timeout -k 10 300 python bench.py --res 512 --batch 16 --precision bf16 --no-cpu-baseline --no-clip > $out/bench_512_bf16.log 2>&1 && grep '^{"metric"' $out/bench_512_bf16.log > $out/${tag}_bench_512_b16_bf16.json
 echo "bench 512 done"
 FUSG_DIST_BACKEND=gloo timeout -k 10 500 python bench.py --gpus 2 --batch 16 --precision f16x3 --no-cpu-baseline --no-clip --no-prof > $out/bench_2rank.log 2>&1 && grep '^{"metric"' $out/bench_2rank.log > $out/${tag}_bench_2ranks_one_card_gloo.json
 echo "2-rank rehearsal done"
