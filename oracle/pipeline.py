@@ -14,8 +14,10 @@ from .vunet import vunet_forward
 
 
 def crop_pass(state_dicts: Dict[str, dict], batch_cpu: Dict[str, torch.Tensor], inpaint: bool = False,
-              seconds: Optional[Dict[str, float]] = None):
-    """`seconds`: optional dict that receives the wall time of each network of this pass (bench.py's cpu_baseline)."""
+              seconds: Optional[Dict[str, float]] = None, deadline: Optional[float] = None):
+    """`seconds`: optional dict that receives the wall time of each network of this pass (bench.py's cpu_baseline).
+    `deadline`: optional time.perf_counter() value; the pass raises TimeoutError after the first network that ends
+    past it (bench.py bounds its thread sweep with this)."""
     out = {}
     t = [time.perf_counter()]
 
@@ -23,6 +25,8 @@ def crop_pass(state_dicts: Dict[str, dict], batch_cpu: Dict[str, torch.Tensor], 
         t.append(time.perf_counter())
         if seconds is not None:
             seconds[name] = t[-1] - t[-2]
+        if deadline is not None and t[-1] > deadline:
+            raise TimeoutError(f"oracle.crop_pass: past the deadline after '{name}'")
 
     hm = hourglass_forward(state_dicts["hg"], batch_cpu["hg_x"])["heatmaps"][-1]
     out["kp_idx"] = heatmap_argmax(hm)

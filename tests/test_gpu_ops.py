@@ -418,8 +418,8 @@ SWEEP_LAYERS = [   # name, cin, cout, k, pad, H, W, pre-op, expected kernel fami
 def test_f16x3_scale_sweep(name, cin, cout, k, pad, H, W, pre, family, precision):
     """the split-fp16 contraction must stay fp32-class when the operands are not O(1).  For operand
     scales {1e-3, 1e-2, 1, 1e2} x {2e-3, 2e-2, 1} the error against an fp64 reference (normalised by |a| * |w|) of the
-    f16x3 kernel is compared with that of the exact-fp32 MFMA kernel on the same launch: bar = 4x (observed ~0.5x,
-    profiles/r02_parity.json)."""
+    f16x3 kernel is compared with that of the exact-fp32 MFMA kernel on the same launch: bar = 2x (observed 0.96-1.27x,
+    profiles/r02_parity.json: the claim is "<= 1.3x the exact-fp32 kernel's error", not "<=")."""
     if precision != "f16x3":
         pytest.skip("compares both kernels itself")
     from conftest import record
@@ -445,8 +445,65 @@ def test_f16x3_scale_sweep(name, cin, cout, k, pad, H, W, pre, family, precision
             record("f32_err_max", e32)
             record("ratio_max", e3 / e32)
             worst = max(worst, e3 / e32)
-            assert e3 <= 4 * e32 + 1e-9, (name, sa, sw, e3, e32)
-    assert worst < 4
+            assert e3 <= 2 * e32 + 1e-9, (name, sa, sw, e3, e32)
+    assert worst < 2
+
+
+def test_f16x3_scale_sweep_fused_bottleneck(precision):
+    """The same sweep for the one-launch hourglass Bottleneck (fusg_hg_bottleneck): three chained contractions with both
+    intermediates kept as split fp16 in LDS.  Input scales {1e-2, 1, 1e2} x weight scales {1e-2, 1, 30} against fp64,
+    compared with the three exact-fp32 launches on the same block: bar = 2x the fp32 path's error (+ 1e-7 of the
+    output's range for the residual's own rounding)."""
+    if precision != "f16x3":
+        pytest.skip("compares both paths itself")
+    from conftest import record
+    worst = 0.0
+    for sa in (1e-2, 1.0, 1e2):
+        for sw in (1e-2, 1.0, 30.0):
+            p, prm = _bneck_params(256, seed=41, scale=sw)
+            x = _rand(2, 256, 16, 16, seed=42, scale=sa)
+            ref = _bneck_ref(x, x, prm)
+            xin = _nhwc(x)
+            got = ops.bottleneck(p, xin)
+            assert ops.last_conv_kernel() == 6
+            if ops.range_exceeded(dev()):                      # an intermediate left the split's range: a legal outcome
+                continue                                       # (the caller redoes the block in fp32), not an accuracy case
+            t = ops.conv(p["c1"], xin, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU, precision="f32")
+            t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision="f32")
+            f32 = ops.conv(p["c3"], t, res0=xin, precision="f32")
+            den = float(ref.abs().max())
+            e3 = float((got.cpu().double() - ref).abs().max()) / den
+            e32 = float((f32.cpu().double() - ref).abs().max()) / den
+            record("bneck_f16x3_rel_err", e3)
+            record("bneck_f32_rel_err", e32)
+            record("bneck_ratio_max", e3 / max(e32, 1e-12))
+            worst = max(worst, e3 / max(e32, 1e-12))
+            assert e3 <= 2 * e32 + 1e-7, (sa, sw, e3, e32)
+    assert worst > 0                                           # at least one in-range combination was compared
+
+
+def test_bf16_halo_scale_sweep(precision):
+    """The single-pass bf16 mode of the halo kernel (precision="bf16", BASELINE configs[4]) over the same operand scales:
+    both operands are rounded to 8 significant bits, so the error normalised by sum|a||w| must stay below 2^-8 (two
+    roundings of 2^-9 each) at EVERY scale - bf16 has fp32's exponent range, there is no range guard to trip - and it
+    is recorded next to the f16x3 error on the same launch (observed ~300x apart: this mode is not fp32-class and is
+    never the headline of an fp32 configuration)."""
+    if precision != "f16x3":
+        pytest.skip("one run is enough")
+    from conftest import record
+    for sa in (1e-3, 1.0, 1e2, 1e6):
+        for sw in (2e-3, 1.0):
+            x = _rand(2, 256, 16, 16, seed=51, scale=sa)
+            w = _rand(64, 256, 3, 3, seed=52, scale=sw)
+            plan = pack.pack_conv(w, None, pad=1)
+            ref = F.conv2d(x.double(), w.double(), None, padding=1)
+            den = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1) + 1e-300
+            got = ops.conv(plan, _nhwc(x), precision="bf16", ksplit=1)
+            assert ops.last_conv_kernel() == 5, ops.last_conv_kernel()
+            assert not ops.range_exceeded(dev())
+            e = float(((got.cpu().double() - ref).abs() / den).max())
+            record("bf16_halo_err_max", e)
+            assert e <= 2.0 ** -8, (sa, sw, e)
 
 
 @pytest.mark.parametrize("name,cin,cout,k,pad,H,W,pre,family", SWEEP_LAYERS[::2])
