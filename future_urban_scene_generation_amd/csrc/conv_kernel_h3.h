@@ -16,7 +16,11 @@
 // 1e-4 .. 1e4 (tools/emu_split.py): 0.3-0.7x the error of an fp32 fmaf chain at K = 2304.
 // Range: |a| >= 2^15 cannot be represented (al' would overflow).  Nothing is clamped: every staged
 // operand feeds a running max |a|, and a workgroup that saw |a| >= 2^15 (or an infinity) raises
-// ConvK::status, on which the caller re-runs the pass in exact fp32 (ops.py).  NaNs propagate.
+// ConvK::status, on which the caller re-runs the pass in exact fp32 (ops.py).  NaNs propagate through the
+// contraction, with ONE documented exception shared by every precision (f32 kernel included): a fused ReLU is
+// fmaxf(v, 0) / v_max3, which returns 0 for a NaN operand (IEEE maxNum), where torch's relu keeps the NaN - a NaN
+// entering a ReLU-fused layer is zeroed and does not raise the status word (v_max3 ignores it).  A NaN anywhere
+// else (no pre-op, ELU, affine without ReLU, weights, residuals) reaches the output as a NaN.
 // Cost: 3 fp16 MFMAs per 16 k instead of 8 fp32 MFMAs: 5.3x less matrix-pipe time; 3 VALU ops per
 // staged element for the split.  Same gather / pre-op / epilogue / split-K machinery as conv_kernel.h.
 // LDS: four fp16 tiles per buffer, [row][32 halves] = 64-byte rows whose four 16-byte chunks are

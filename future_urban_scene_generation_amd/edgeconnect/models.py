@@ -32,7 +32,7 @@ class BaseModel(nn.Module):
         reference's checkpoint contract, edgeconnect/models.py:25-30); a missing file leaves the initial weights."""
         if not os.path.exists(self.gen_weights_path):
             return
-        ckpt = torch.load(self.gen_weights_path, map_location="cpu")
+        ckpt = torch.load(self.gen_weights_path, map_location="cpu", weights_only=True)
         self.generator.load_state_dict(ckpt["generator"])
         self.iteration = ckpt["iteration"]
 

@@ -151,12 +151,19 @@ class FusedNet(nn.Module):
         super().__init__()
         self._plans = None
         self._plans_dev = None
+        self._generation = 0
 
     # -- cache invalidation -----------------------------------------------------------------
     def refresh(self) -> None:
-        """Drop the packed-weight cache (call after modifying parameters in place)."""
+        """Drop the packed-weight cache (call after modifying parameters in place).  Bumps `generation`: a recorded
+        pass (pipeline.CompiledPass) holds device pointers into the old cache and refuses to replay after this."""
         self._plans = None
         self._plans_dev = None
+        self._generation = getattr(self, "_generation", 0) + 1
+
+    @property
+    def generation(self) -> int:
+        return getattr(self, "_generation", 0)
 
     def load_state_dict(self, *args, **kwargs):
         r = super().load_state_dict(*args, **kwargs)

@@ -79,7 +79,10 @@ class precision:
 # per device, here.  The module entry points (nn_base.range_guarded) and VehiclePipeline.run read it after their
 # launches and redo the call in exact fp32 when it is set, so a result computed from a saturated operand never
 # reaches the caller.
+# Single-threaded by contract, like the reference's callers (Threading): `_GUARD`, `_STATUS_SCOPE`,
+# `PRECISION` and `RECORDER` are process-wide, not per-thread.
 _STATUS = {}
+_STATUS_SCOPE = []                       # innermost `status_scope` word; empty: the device's default word
 _GUARD = {"depth": 0, "deferred": 0}
 
 
@@ -94,18 +97,43 @@ def halo_precision() -> bool:
     return PRECISION in ("f16x3", "bf16")
 
 
+def new_status_word(device) -> torch.Tensor:
+    return torch.zeros(4, dtype=torch.int32, device=torch.device(device))
+
+
 def status_word(device) -> torch.Tensor:
+    """The word the launches issued NOW report to: the innermost `status_scope`'s, else the device's default one
+    (what the module entry points read)."""
+    if _STATUS_SCOPE:
+        return _STATUS_SCOPE[-1]
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     w = _STATUS.get(key)
     if w is None:
-        w = _STATUS[key] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", key))
+        w = _STATUS[key] = new_status_word(torch.device("cuda", key))
     return w
 
 
-def range_exceeded(device, clear: bool = True) -> bool:
-    """Has any f16x3 launch on `device` since the last clear seen an operand outside the split's range?
-    Synchronises the current stream (a 4-byte read)."""
-    w = status_word(device)
+class status_scope:
+    """Launches issued inside report their range status to `word` instead of the device's default word.  A
+    VehiclePipeline owns one: passes issued with check="async" then cannot be cleared (or mistaken for its own) by a
+    module entry point called between them and `finish()` - each reader only ever sees the launches it issued."""
+
+    def __init__(self, word: torch.Tensor):
+        self.word = word
+
+    def __enter__(self):
+        _STATUS_SCOPE.append(self.word)
+        return self
+
+    def __exit__(self, *exc):
+        _STATUS_SCOPE.pop()
+        return False
+
+
+def range_exceeded(device, clear: bool = True, word: Optional[torch.Tensor] = None) -> bool:
+    """Has any f16x3 launch reporting to `word` (default: the current scope's / the device's word) since the last
+    clear seen an operand outside the split's range?  Synchronises the current stream (a 4-byte read)."""
+    w = status_word(device) if word is None else word
     hit = bool(w[0].item())
     if hit and clear:
         w.zero_()
@@ -299,6 +327,8 @@ def _splitk_counters(device) -> torch.Tensor:
     c = _COUNTERS.get(key)
     if c is None:
         c = _COUNTERS[key] = torch.zeros(N_COUNTERS, device=device, dtype=torch.int32)
+    if RECORDER is not None:
+        RECORDER.keep.append(c)
     return c
 
 
@@ -310,6 +340,11 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((max(nbytes, 1 << 22) + 3) // 4, device=device, dtype=torch.float32)
         _WS[key] = ws
+    if RECORDER is not None:
+        # a recorded pass replays this address: it must outlive a later, larger eager pass that replaces _WS[key]
+        # (the old block would go back to the caching allocator and be handed to someone else while the plan still
+        # writes split-K partial sums into it)
+        RECORDER.keep.append(ws)
     return ws
 
 
@@ -330,6 +365,10 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
     symmetric (transposed-conv phases; zero padding only).  stats_into = (buffer [B, slots, cout, 2], first_slot): write
     this launch's fused statistics slots there (the launch must qualify)."""
     plan.to(x0.device)
+    if RECORDER is not None:
+        RECORDER.keep.append(plan.dev)             # packed weights / tables the recorded launch points into
+        if pre is not None:
+            RECORDER.keep.append(pre)
     b, c0, h, w = x0.shape
     assert c0 == plan.c_split[0], (x0.shape, plan.c_split)
     if len(plan.c_split) > 1:
@@ -465,8 +504,12 @@ def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> 
     d = L.BneckDesc()
     d.x, d.res, d.dst = desc(x), desc(res), desc(out)
     d.pre_scale, d.pre_shift = p["pre"][0].data_ptr(), p["pre"][1].data_ptr()
+    if RECORDER is not None:
+        RECORDER.keep.append(p["pre"])
     for i, key in ((1, "c1"), (2, "c2"), (3, "c3")):
         dev = p[key].to(x.device).dev
+        if RECORDER is not None:
+            RECORDER.keep.append(dev)
         assert dev.get("wfrag") is not None and dev["wfrag_order"] == 0, key
         setattr(d, "w%dfrag" % i, dev["wfrag"].data_ptr())
         setattr(d, "bias%d" % i, dev["bias"].data_ptr())

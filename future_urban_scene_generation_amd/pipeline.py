@@ -133,6 +133,8 @@ class VehiclePipeline:
             nets += [self.edge, self.inp]
         for n in nets:
             n.to(self.device).eval()
+        self._nets = nets
+        self._status = None                       # this pipeline's own range-status word (ops.status_scope), made on first use
 
     # The networks of one crop pass do not depend on each other (hourglass / ICN / VUnet; edge -> inpaint is one
     # chain), so each branch runs on its own HIP stream: the many small, latency-bound launches of the hourglass
@@ -223,16 +225,26 @@ class VehiclePipeline:
     # left the split's range, redo the pass in exact fp32 - the returned tensors are always valid.  check="async":
     # return without synchronising (the caller keeps issuing passes); the status word is sticky, and `finish()`
     # says whether any pass since the last call was affected - call it before consuming outputs.
+    def status_word(self) -> torch.Tensor:
+        """The range-status word this pipeline's passes report to - its own, not the device-wide one the module entry
+        points read and clear: an entry-point call between async passes and `finish()` can neither clear nor inherit
+        a flag raised by those passes."""
+        from . import ops
+        if self._status is None:
+            self._status = ops.new_status_word(self.device)
+        return self._status
+
     def _guarded(self, fn, args, check: str, rng_state):
         from . import ops
         if not ops.range_guarded() or check is None:
             return fn(*args)
-        with ops.defer_range_check():
+        word = self.status_word()
+        with ops.defer_range_check(), ops.status_scope(word):
             out = fn(*args)
         if check == "async":
             return out
         with torch.cuda.device(self.device):
-            hit = ops.range_exceeded(self.device)
+            hit = ops.range_exceeded(self.device, word=word)
         if not hit:
             return out
         if rng_state is not None:
@@ -249,7 +261,7 @@ class VehiclePipeline:
         if not ops.range_guarded():
             return False
         with torch.cuda.device(self.device):
-            return ops.range_exceeded(self.device)
+            return ops.range_exceeded(self.device, word=self.status_word())
 
     def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
             check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
@@ -365,13 +377,15 @@ class CompiledPass:
                 L.check(L.lib().fusg_plan_begin(self.rec.handle), "plan_begin")
                 ops.RECORDER = self.rec
                 try:
-                    with ops.defer_range_check():
+                    with ops.defer_range_check(), ops.status_scope(pipe.status_word()):
                         self.outputs = pipe._run(self.inputs, vehicle_seeds)
                 finally:
                     ops.RECORDER = None
                     L.check(L.lib().fusg_plan_end(self.rec.handle), "plan_end")
             torch.cuda.synchronize(self.device)
         self.size = int(L.lib().fusg_plan_size(self.rec.handle))
+        # the plan holds raw pointers into each network's packed-weight cache: remember which cache it was recorded on
+        self.generations = [n.generation for n in pipe._nets]
 
     def __del__(self):
         try:
@@ -411,11 +425,15 @@ class CompiledPass:
                 raise RuntimeError("CompiledPass.run: the current stream differs from the one the pass was recorded on")
             if ops.PRECISION != self.precision:
                 raise RuntimeError(f"CompiledPass.run: recorded with precision {self.precision}, now {ops.PRECISION}")
+            if [n.generation for n in self.pipe._nets] != self.generations:
+                raise RuntimeError("CompiledPass.run: a network's parameters changed (load_state_dict / .to() / refresh()) "
+                                   "after this pass was recorded - its launches point into the old packed weights; "
+                                   "call pipe.compile() again")
             rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync" and ops.range_guarded()) else None
             out = self._issue(batch, vehicle_seeds)
             if not ops.range_guarded() or check != "sync":
                 return out
-            if not ops.range_exceeded(self.device):
+            if not ops.range_exceeded(self.device, word=self.pipe.status_word()):
                 return out
             if rng is not None:
                 torch.set_rng_state(rng)

@@ -425,7 +425,7 @@ def test_edgeconnect_checkpoint_roundtrip(tmp_path):
     src.generator.load_state_dict(synth_sd("inpaint"))
     src.iteration = 1234
     src.save()
-    blob = torch.load(str(tmp_path / "InpaintingModel_gen.pth"), map_location="cpu")
+    blob = torch.load(str(tmp_path / "InpaintingModel_gen.pth"), map_location="cpu", weights_only=True)
     assert set(blob.keys()) == {"iteration", "generator"} and list(blob["generator"].keys()) == list(load_schema("inpaint").keys())
     dst = InpaintingModel(cfg)
     dst.load()
@@ -471,6 +471,57 @@ def test_compiled_pass_replays_the_eager_pass(precision):
             want = pipe.run(bad, vehicle_seeds=[1, 2])
         assert all(torch.equal(got[k], want[k]) for k in want)
         assert not ops.range_exceeded(DEV)
+
+
+def test_compiled_pass_survives_a_larger_eager_pass_and_refuses_stale_weights(precision):
+    """a recorded pass bakes raw device pointers.  (1) The split-K workspace it was recorded with must outlive
+    a later, larger eager pass on the same stream that replaces ops._WS[...] (the old block used to go back to the
+    caching allocator while the plan kept writing partial sums into it): compile(B=1), eager run(B=16), then churn the
+    allocator - the replay must still equal the eager pass bit for bit.  (2) After a network's parameters changed
+    (load_state_dict -> refresh) the plan points into freed packed weights: run() must refuse."""
+    if precision != "f16x3":
+        pytest.skip("one precision is enough")
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    pipe = VehiclePipeline(DEV)
+    b1 = synth_batch(1, 128, DEV, seed=3)
+    cp = pipe.compile(b1, vehicle_seeds=[5])
+    want = {k: v.clone() for k, v in pipe.run(b1, vehicle_seeds=[5]).items()}
+    big = synth_batch(16, 128, DEV, seed=4)
+    pipe.run(big, vehicle_seeds=list(range(16)))                  # grows the per-stream split-K workspaces
+    torch.cuda.synchronize()
+    junk = [torch.full((1 << 20,), float(i), device=DEV) for i in range(64)]   # reuse whatever the allocator got back
+    got = cp.run(b1, vehicle_seeds=[5])
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    del junk
+    pipe.icn.load_state_dict(pipe.icn.state_dict())               # same values, new packed-weight cache
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        cp.run(b1, vehicle_seeds=[5])
+    cp2 = pipe.compile(b1, vehicle_seeds=[5])
+    got = cp2.run(b1, vehicle_seeds=[5])
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_async_range_flag_is_not_consumed_by_an_entry_point_call(precision):
+    """the pipeline's passes report to the pipeline's own status word.  An out-of-range pass issued with
+    check="async", then a clean module entry-point call (which reads and clears the DEVICE word), then finish(): the
+    flag must still be there - and the entry point must not have repeated its own call in fp32 because of it."""
+    if precision != "f16x3":
+        pytest.skip("f16x3 only")
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    pipe = VehiclePipeline(DEV)
+    bad = synth_batch(1, 128, DEV, seed=1)
+    bad["icn_x"][0, 0, 0, 0] = 1e6
+    assert not pipe.finish()
+    pipe.run(bad, vehicle_seeds=[1], check="async")
+    x = synth_inputs("icn", 1, 64)["x"].to(DEV)
+    y = model("icn")(x)                                          # entry point: reads the device word, which is clean
+    with ops.precision("f32"):
+        y32 = model("icn")(x)
+    assert not torch.equal(y, y32)                                # it ran in f16x3, not a needless fp32 repeat
+    assert pipe.finish() is True                                  # the async pass's flag survived
+    assert pipe.finish() is False
 
 
 def test_vunet_and_edgeconnect_at_512(precision):

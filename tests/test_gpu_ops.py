@@ -506,6 +506,28 @@ def test_bf16_halo_scale_sweep(precision):
             assert e <= 2.0 ** -8, (sa, sw, e)
 
 
+def test_nan_inputs_propagate_except_through_a_fused_relu(precision):
+    """ADVICE r2 (documented behaviour, csrc/conv_kernel_h3.h header): a NaN activation reaches every output it feeds
+    on both contractions - except through a fused ReLU, where fmaxf(NaN, 0) = 0 on BOTH precisions (torch's relu
+    would keep it).  The two precisions agree with each other in every case."""
+    x = _rand(1, 64, 16, 16, seed=61)
+    x[0, 5, 8, 8] = float("nan")
+    w = _rand(32, 64, 3, 3, seed=62, scale=0.05)
+    plan = pack.pack_conv(w, None, pad=1)
+    for pre in (L.PRE_NONE, L.PRE_ELU):
+        got = ops.conv(plan, _nhwc(x), pre_op=pre, ksplit=1).cpu()
+        assert bool(torch.isnan(got[0, :, 7:10, 7:10]).all()), pre      # the 3x3 neighbourhood, all channels
+        assert int(torch.isnan(got).sum()) == 32 * 9
+    ops.range_exceeded(dev())
+    got = ops.conv(plan, _nhwc(x), pre_op=L.PRE_RELU, ksplit=1).cpu()
+    xz = x.clone()
+    xz[0, 5, 8, 8] = 0.0
+    ref = F.conv2d(F.relu(xz).double(), w.double(), None, padding=1)
+    assert not bool(torch.isnan(got).any())
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    ops.range_exceeded(dev())
+
+
 @pytest.mark.parametrize("name,cin,cout,k,pad,H,W,pre,family", SWEEP_LAYERS[::2])
 def test_f16x3_out_of_range_raises_status(name, cin, cout, k, pad, H, W, pre, family, precision):
     """An operand the split cannot represent (|x| >= 2^15, inf) is never clamped silently: the launch raises the
