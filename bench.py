@@ -72,10 +72,12 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=8, help="crops in the CPU baseline sample")
     ap.add_argument("--no-clip", action="store_true", help="skip the secondary clip-mode figure")
     ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (second pass with per-launch HIP events)")
-    ap.add_argument("--broadcast-weights", action="store_true",
-                    help="N > 1: only rank 0 builds the (synthetic) checkpoints, the others receive them through "
-                         "pipeline.broadcast_state_dicts (RCCL broadcast of one flat blob per network) instead of "
-                         "rebuilding them from the seed")
+    ap.add_argument("--broadcast-weights", dest="broadcast_weights", action="store_true", default=True,
+                    help="N > 1 (default): only rank 0 builds the checkpoints, the others receive them through "
+                         "pipeline.broadcast_state_dicts (RCCL broadcast of one flat blob per network) - what a real "
+                         "checkpoint read on rank 0 needs")
+    ap.add_argument("--no-broadcast-weights", dest="broadcast_weights", action="store_false",
+                    help="N > 1: every rank rebuilds the synthetic weights from the seed instead (no start-up collective)")
     ap.add_argument("--replay", action="store_true",
                     help="issue each pass as ONE recorded-plan replay (fusg_plan) instead of ~370 launches from Python: "
                          "matters at small --batch, where the interpreter bounds the pass")
@@ -316,6 +318,14 @@ def main():
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, shard_range, synth_batch
 
     torch.set_grad_enabled(False)
+    if world > 1:
+        # N ranks share one host: each draws its VUnet noise with torch.randn on the CPU and issues ~370 launches
+        # per pass - without a cap every rank starts a thread pool as wide as the machine
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            ncpu = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(16, ncpu // world)))
     sds, bcast_ms = None, None
     if args.broadcast_weights and world > 1:
         from future_urban_scene_generation_amd.pipeline import broadcast_state_dicts, load_schema
@@ -539,7 +549,8 @@ def main():
             line["per_rank_crops_per_s"] = h.get("per_rank_crops_per_s")
             line["gather_enqueue_ms_per_step"] = h.get("gather_enqueue_ms_per_step")
             line["weights"] = ("broadcast from rank 0 (%.0f ms, one flat blob per network)" % bcast_ms) if bcast_ms is not None \
-                else "every rank builds them from the seed (--broadcast-weights: RCCL broadcast from rank 0)"
+                else "every rank builds them from the seed (--no-broadcast-weights)"
+            line["host_threads_per_rank"] = torch.get_num_threads()
         line.update(extra)
         if h.get("power") is not None:
             line["power"] = h["power"]

@@ -29,10 +29,16 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_GATHER_BUFS = {}
+
+
 def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0) -> Optional[torch.Tensor]:
     """Gather per-rank shards ([n_local, ...], same trailing shape) to `dst` in vehicle order.
     Works for any backend (RCCL on GPU tensors, gloo on CPU tensors).  Returns the full tensor on
-    `dst`, None elsewhere.  Shards may be ragged (n_items not a multiple of the world size)."""
+    `dst`, None elsewhere.  Shards may be ragged (n_items not a multiple of the world size).
+    The padded send buffer and rank `dst`'s receive buffers are allocated ONCE per (shape, dtype, device, world) and
+    reused by every later call (a frame loop calls this once per pass): the result is a fresh tensor, the staging
+    buffers never escape."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
@@ -41,13 +47,18 @@ def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0)
     max_n = max(hi - lo for lo, hi in sizes)
     if local.is_cuda and dist.get_backend(group) == "gloo":       # rehearsal of the multi-rank path without RCCL
         local = local.cpu()
-    pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst, group=group)
+    key = (max_n, tuple(local.shape[1:]), local.dtype, str(local.device), world, rank == dst, id(group))
+    bufs = _GATHER_BUFS.get(key)
+    if bufs is None:
+        pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        recv = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        bufs = _GATHER_BUFS[key] = (pad, recv)
+    pad, recv = bufs
+    pad[: local.shape[0]].copy_(local)                             # (rows past a short shard keep their zeros: never read)
+    dist.gather(pad, recv, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    return torch.cat([recv[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
 def broadcast_state_dicts(state_dicts: Optional[Dict[str, dict]], nets: Sequence[str] = ("hg", "icn", "vunet"),
@@ -105,7 +116,12 @@ def load_schema(net: str):
 class VehiclePipeline:
     """Holds the five networks on one device and runs batches of crops through them."""
 
-    def __init__(self, device, inpaint: bool = False, state_dicts: Optional[Dict[str, dict]] = None, seed: int = 0):
+    def __init__(self, device, inpaint: bool = False, state_dicts: Optional[Dict[str, dict]] = None, seed: int = 0,
+                 broadcast_src: Optional[int] = None, group=None):
+        """state_dicts: checkpoints (the reference's keys) per network; a missing network gets the synthetic weights of
+        `seed`.  broadcast_src: with an initialised process group, only that rank needs to hold `state_dicts` (a real
+        checkpoint read from disk on rank 0): they are distributed with `broadcast_state_dicts` first (north_star: RCCL
+        broadcast of the shared weights), so every rank renders with identical parameters."""
         from .edgeconnect.models import EdgeModel, InpaintingModel
         from .stacked_hourglass.models import HourglassNet
         from .synth import synth_state_dict
@@ -113,6 +129,13 @@ class VehiclePipeline:
         from .warp_learn.models import G_Resnet
         self.device = torch.device(device)
         self.inpaint = inpaint
+        if broadcast_src is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                nets_ = ("hg", "icn", "vunet") + (("edge", "inpaint") if inpaint else ())
+                coll_dev = self.device if dist.get_backend(group) == "nccl" else "cpu"
+                state_dicts = broadcast_state_dicts(state_dicts if dist.get_rank(group) == broadcast_src else None,
+                                                    nets=nets_, src=broadcast_src, group=group, device=coll_dev)
 
         def sd(net):
             if state_dicts is not None and net in state_dicts:

@@ -38,6 +38,7 @@ def _worker(rank, world, port, n_items, q):
     try:
         lo, hi = shard_range(n_items, rank, world)
         local = _fake_render(list(range(lo, hi)))
+        gather_in_order(_fake_render(list(range(hi, lo, -1))), n_items)     # an earlier pass: the staging buffers are reused
         full = gather_in_order(local, n_items)
         kp = gather_in_order(torch.arange(lo, hi, dtype=torch.int32).view(-1, 1).repeat(1, 12), n_items)
         if rank == 0:
@@ -55,8 +56,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 8), (2, 7), (3, 10)])
+@pytest.mark.parametrize("world,n_items", [(2, 8), (2, 7), (3, 10), (8, 64)])
 def test_gather_in_vehicle_order(world, n_items):
+    """(8, 64) = BASELINE configs[3]'s shape: 64 vehicles of one frame, 8 shards of 8 (gloo rehearsal of --gpus 8
+    --vehicles 64; RCCL itself has never run in the development loop)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -9,6 +9,7 @@ observation of the round, not a generic tolerance:
   * to_image-quantised uint8 images: |diff| <= 1 LSB and SSIM >= 0.999 (north_star bar).
 """
 from argparse import Namespace
+import os
 
 import numpy as np
 import pytest
@@ -307,6 +308,38 @@ def test_full_size_batch_permutation_equivariance(precision, inpaint):
         assert np.array_equal(v.cpu().numpy(), out[k][perm.numpy()]), k
     assert out["icn_u8"].std() > 10 and out["vunet_u8"].std() > 10          # not a degenerate image
     assert len({tuple(r) for r in out["kp_idx"].tolist()}) > 1
+
+
+@pytest.mark.parametrize("inpaint", [False, True], ids=["cfg1", "cfg2_inpaint"])
+def test_full_size_batch_against_the_oracle(precision, inpaint):
+    """BASELINE configs[1] / configs[2] at FULL size (B=32, 256x256) against the CPU oracle itself (about
+    11 s / 25 s of host time at 16 threads - bench.py measured the oracle at ~2.9 crops/s), with the reference's own noise
+    contract: ONE `torch.randn(B, 128, h, w)` per sampler on the global CPU generator (vunet/layers.py:163-167), no
+    per-vehicle seeds.  Keypoint indices bit-exact, uint8 images within 1 LSB, SSIM >= 0.999 (north_star's bar)."""
+    if precision != "f16x3":
+        pytest.skip("one precision is enough at this size")
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    B, R = 32, 256
+    nets = ("hg", "icn", "vunet") + (("edge", "inpaint") if inpaint else ())
+    sds = {n: synth_sd(n) for n in nets}
+    pipe = VehiclePipeline(DEV, inpaint=inpaint, state_dicts=sds)
+    batch = synth_batch(B, R, "cpu", inpaint=inpaint, seed=5)
+    torch.manual_seed(123)
+    got = {k: v.cpu().numpy() for k, v in pipe.run({k: v.to(DEV) for k, v in batch.items()}).items()}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, len(os.sched_getaffinity(0)))))
+    try:
+        torch.manual_seed(123)
+        ref = oracle.crop_pass(sds, batch, inpaint)
+    finally:
+        torch.set_num_threads(nt)
+    assert np.array_equal(got["kp_idx"], ref["kp_idx"])
+    for k in ("icn_u8", "vunet_u8") + (("inpaint_u8",) if inpaint else ()):
+        d = int(np.abs(got[k].astype(int) - ref[k].astype(int)).max())
+        sv = oracle.ssim(got[k], ref[k])
+        record(f"full_size_{k}_max_diff", d)
+        record(f"full_size_{k}_ssim", sv)
+        assert d <= 1 and sv >= 0.999, (k, d, sv)
 
 
 @pytest.mark.parametrize("H,W", [(64, 96), (72, 88)])
@@ -699,3 +732,17 @@ def test_config3_frame_of_64_vehicles_in_8_shards(precision):
         d = int(np.abs(got[k].astype(int) - full[k].astype(int)).max())
         record(f"{k}_max_diff_sharded_vs_whole", d)
         assert d <= 1, k
+    # ... and against the CPU oracle on 8 of the 64 vehicles (one per shard): the oracle renders vehicle v alone with the
+    # global generator seeded like v's own stream - the same draws, because a vehicle's stream is consumed in the
+    # reference's sampler order with the reference's shapes minus the batch axis
+    sds = {k: synth_sd(k) for k in ("hg", "icn", "vunet")}
+    cpu_frame = {k: v.cpu() for k, v in frame.items()}
+    for v in range(3, n, 8):
+        torch.manual_seed(seeds[v])
+        ref = oracle.crop_pass(sds, {k: t[v:v + 1] for k, t in cpu_frame.items()})
+        assert np.array_equal(full["kp_idx"][v:v + 1], ref["kp_idx"]), v
+        for k in ("icn_u8", "vunet_u8"):
+            d = int(np.abs(full[k][v:v + 1].astype(int) - ref[k].astype(int)).max())
+            sv = oracle.ssim(full[k][v:v + 1], ref[k])
+            record(f"cfg3_{k}_max_diff_vs_oracle", d)
+            assert d <= 1 and sv >= 0.999, (v, k, d, sv)
