@@ -31,7 +31,8 @@ Extra fields: "roofline" (conv kernels: algorithmic FLOPs of SURVEY.md §8d - an
 by the kernels' HIP-event time on the launch stream, measured live in a second pass of the same K steps),
 "cpu_baseline" (the CPU oracle = a port of the reference's torch graph, timed on this host's cores on a bounded
 sample of the same workload, the whole leg capped at 60 s; N=1, rank 0 only), "ssim_vs_cpu_ref" / "kp_idx_exact" (quality of the GPU path on
-that very sample) and "clip_mode" (secondary figure: 8 vehicles x 6 frames).
+that very sample), "clip_mode" (secondary figure: 8 vehicles x 6 frames) and "frame_mode" (secondary figure: the
+chained per-frame driver run_frame, 8 vehicles on a 720 x 1280 frame).
 """
 import argparse
 import json
@@ -524,6 +525,27 @@ def main():
                               "vehicle_clips_per_s": round(V / cdt, 2), "frames_per_s": round(V * F / cdt, 1),
                               "range_status_raised": bool(bad)}
         del clip
+        # secondary figure: frame mode = the chained per-frame driver (VehiclePipeline.run_frame: detector boxes -> box
+        # crops -> hourglass -> argmax -> pose fit, plane warps -> ICN inputs -> ICN -> Lab image, VUnet inputs -> VUnet,
+        # resize-back + ordered paste of every vehicle), 8 vehicles on a 720 x 1280 frame, everything device-resident;
+        # the host part per frame = the 2 x 5 homography fits per vehicle and the pose fit's 4 x 7-number epilogue
+        if args.res == 256:
+            from future_urban_scene_generation_amd.pipeline import synth_frame
+            FV = 8
+            scene = synth_frame(FV, (720, 1280), dev, seed=3)
+            scene["vehicle_seeds"] = list(range(FV))
+            pipe.run_frame(scene)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                pipe.run_frame(scene)
+            torch.cuda.synchronize()
+            fdt = (time.perf_counter() - t1) / 3
+            extra["frame_mode"] = {"vehicles": FV, "frame": "720x1280", "ms_per_frame": round(fdt * 1e3, 3),
+                                   "vehicles_per_s": round(FV / fdt, 2),
+                                   "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
+                                               "paste-back of both composited frames; range check per frame (sync)"}
+            del scene
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, quality = cpu_baseline_leg(args, batch, pipe, torch)

@@ -25,12 +25,26 @@ _ALIASES = {
 }
 
 
-def install(names=None) -> None:
+# opt-in only: the uint8 image steps (to_image, warp_unwarp_planes, get_planes, planes_to_torch) restate OpenCV's
+# arithmetic and their parity with a particular OpenCV build is unpinned (oracle/cv_host.py)
+_OPT_IN_ALIASES = {"warp_learn.planes_utils": "future_urban_scene_generation_amd.warp_learn.planes_utils"}
+
+
+def install(names=None, planes_utils=None) -> None:
     """Register the drop-in modules in ``sys.modules`` under the reference's import names.
 
-    Only the network modules are replaced; ``warp_learn`` and ``edgeconnect`` keep resolving their
-    other sub-modules (planes_utils, config, ...) from the reference checkout on ``sys.path``."""
-    for alias, target in _ALIASES.items():
+    Only the network modules (and the pose fit) are replaced; ``warp_learn`` and ``edgeconnect`` keep resolving their
+    other sub-modules (config, online_visibility, ...) from the reference checkout on ``sys.path``.
+    ``planes_utils=True`` (or FUSG_DROPIN_PLANES_UTILS=1 in the environment) additionally routes
+    ``from warp_learn.planes_utils import to_image, warp_unwarp_planes`` (trajectory_inference.py:28-29) to the device
+    versions - explicit, because their parity with OpenCV is unpinned."""
+    import os
+    if planes_utils is None:
+        planes_utils = os.environ.get("FUSG_DROPIN_PLANES_UTILS") == "1"
+    aliases = dict(_ALIASES)
+    if planes_utils:
+        aliases.update(_OPT_IN_ALIASES)
+    for alias, target in aliases.items():
         if names is not None and alias.split(".")[0] not in names:
             continue
         mod = importlib.import_module(target)

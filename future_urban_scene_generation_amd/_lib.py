@@ -105,6 +105,10 @@ _SIGS = {
     "fusg_icn_inputs": (C.c_int, [_TP, _TP, _TP, C.c_void_p, _TP, C.c_void_p]),
     "fusg_lab2bgr_u8": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_paste_back_u8": (C.c_int, [_TP, _TP, C.c_void_p, _TP, C.c_void_p]),
+    "fusg_crop_resize_u8": (C.c_int, [_TP, C.c_void_p, _TP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fusg_vunet_inputs": (C.c_int, [_TP, _TP, _TP, _TP, C.c_void_p, _TP, _TP, C.c_void_p]),
+    "fusg_mask_bbox_geom": (C.c_int, [_TP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fusg_keypoints_to_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "fusg_pnp_cpc": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p] * 4),
     "fusg_plan_create": (C.c_void_p, []),
     "fusg_plan_destroy": (None, [C.c_void_p]),

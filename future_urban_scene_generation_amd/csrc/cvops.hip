@@ -324,6 +324,156 @@ __global__ __launch_bounds__(256) void paste_back_kernel(PasteIn a, long total) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ frame-chain glue
+// The steps of trajectory_inference.py:55-79, 200-228 between the uint8 frame and the networks' float inputs, so that a
+// frame's vehicles go from detector boxes to rendered crops without leaving the device (pipeline.VehiclePipeline.run_frame).
+
+// bilinear sample of a crop window (geom row g, as in IcnIn) of `img` resized to out_w x out_h: cv::resize INTER_LINEAR
+template <class Fetch>
+__device__ __forceinline__ void crop_resize_px(const int* g, int out_w, int out_h, int x, int y, Fetch fetch, int rgb[3]) {
+    const int cw = g[2] - g[0], ch = g[3] - g[1];
+    const int ox = g[0] - g[4], oy = g[1] - g[5];
+    if (cw <= 0 || ch <= 0) { rgb[0] = rgb[1] = rgb[2] = 0; return; }
+    if (cw == out_w && ch == out_h) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = fetch(ox + x, oy + y, c);
+        return;
+    }
+    int sx, ax0, ax1, sy, ay0, ay1;
+    resize_coef(x, cw, out_w, sx, ax0, ax1);
+    resize_coef(y, ch, out_h, sy, ay0, ay1);
+    const int sx1 = sx + 1 < cw ? sx + 1 : cw - 1, sy1 = sy + 1 < ch ? sy + 1 : ch - 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = fetch(ox + sx, oy + sy, c) * ax0 + fetch(ox + sx1, oy + sy, c) * ax1;
+        const int S1 = fetch(ox + sx, oy + sy1, c) * ax0 + fetch(ox + sx1, oy + sy1, c) * ax1;
+        const int o = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        rgb[c] = o < 0 ? 0 : (o > 255 ? 255 : o);
+    }
+}
+
+// square_crop_from_bbox + cv2.resize for V windows (trajectory_inference.py:58-60; warp_learn/vehicle_utils.py:40-52),
+// output uint8 HWC (mode 0), ToTensor + normalize (mode 1: (v/255 - mean) / std, trajectory_inference.py:61-64) or
+// to_tensor (mode 2: v/255*2 - 1, utils/misc_utils.py:35-49) as f32 NHWC-physical.
+struct CropIn { U8View src; const int* geom; U8View dst8; float* dstf; long dsn, dsh, dsw; int V, out_h, out_w, mode, src_per_v; float mean[3], stdv[3]; };
+__global__ __launch_bounds__(256) void crop_resize_kernel(CropIn a, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.out_w);
+    long r = idx / a.out_w;
+    const int y = (int)(r % a.out_h);
+    const int v = (int)(r / a.out_h);
+    const unsigned char* img = a.src.p + (a.src_per_v ? (long)v * a.src.sn : 0);
+    const U8View& sv = a.src;
+    int rgb[3];
+    crop_resize_px(a.geom + v * 8, a.out_w, a.out_h, x, y, [&](int px, int py, int c) { return crop_fetch(img, sv, px, py, c); }, rgb);
+    if (a.mode == 0) {
+        unsigned char* d = a.dst8.p + (long)v * a.dst8.sn + (long)y * a.dst8.sh + (long)x * a.dst8.sw;
+        d[0] = (unsigned char)rgb[0]; d[1] = (unsigned char)rgb[1]; d[2] = (unsigned char)rgb[2];
+        return;
+    }
+    float* d = a.dstf + (long)v * a.dsn + (long)y * a.dsh + (long)x * a.dsw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float f = (float)rgb[c] / 255.f;
+        d[c] = a.mode == 1 ? (f - a.mean[c]) / a.stdv[c] : f * 2.f - 1.f;
+    }
+}
+
+// The VUnet's inputs (trajectory_inference.py:203-228): x = cat[to_tensor(masked frame crop), to_tensor(src sketch
+// crop, channels reversed)], y_tilde = to_tensor(dst sketch crop, channels reversed); all three crops use the square
+// window of the vehicle mask's bounding box, resized to out_w x out_h; masked-frame pixels whose (resized) src sketch
+// is all zero become 255.
+struct VuIn { U8View frame, mask, ssk, dsk; const int* geom; float* x; long xsn, xsh, xsw; float* y; long ysn, ysh, ysw; int V, out_h, out_w; };
+__global__ __launch_bounds__(256) void vunet_inputs_kernel(VuIn a, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.out_w);
+    long r = idx / a.out_w;
+    const int y = (int)(r % a.out_h);
+    const int v = (int)(r / a.out_h);
+    const int* g = a.geom + v * 8;
+    const unsigned char* mk = a.mask.p + (long)v * a.mask.sn;
+    const unsigned char* s1 = a.ssk.p + (long)v * a.ssk.sn;
+    const unsigned char* s2 = a.dsk.p + (long)v * a.dsk.sn;
+    int mf[3], ss[3], ds[3];
+    crop_resize_px(g, a.out_w, a.out_h, x, y, [&](int px, int py, int c) {
+        if (!((unsigned)px < (unsigned)a.frame.w && (unsigned)py < (unsigned)a.frame.h)) return 0;
+        return mk[(long)py * a.mask.sh + (long)px * a.mask.sw] ? (int)a.frame.p[(long)py * a.frame.sh + (long)px * a.frame.sw + c] : 0;
+    }, mf);
+    crop_resize_px(g, a.out_w, a.out_h, x, y, [&](int px, int py, int c) { return crop_fetch(s1, a.ssk, px, py, c); }, ss);
+    crop_resize_px(g, a.out_w, a.out_h, x, y, [&](int px, int py, int c) { return crop_fetch(s2, a.dsk, px, py, c); }, ds);
+    if ((ss[0] | ss[1] | ss[2]) == 0) mf[0] = mf[1] = mf[2] = 255;
+    float* dx = a.x + (long)v * a.xsn + (long)y * a.xsh + (long)x * a.xsw;
+    float* dy = a.y + (long)v * a.ysn + (long)y * a.ysh + (long)x * a.ysw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dx[c] = (float)mf[c] / 255.f * 2.f - 1.f;
+        dx[3 + c] = (float)ss[2 - c] / 255.f * 2.f - 1.f;
+        dy[c] = (float)ds[2 - c] / 255.f * 2.f - 1.f;
+    }
+}
+
+// Bounding box of the non-zero pixels of V masks (np.nonzero + min / max, warp_learn/models.py:333-336,
+// trajectory_inference.py:204-206) and the square-crop geometry row of that box (utils/crop_utils.py:4-50), on the
+// device: bbox [V][4] = (x_min, y_min, x_max, y_max), geom [V][8] as in IcnIn; an empty mask gives an all-zero geom
+// row (cw = ch = 0: the consumers write zeros / paste nothing - the reference raises and skips the vehicle).
+__global__ __launch_bounds__(256) void bbox_init_kernel(int* bbox, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) bbox[i] = (i & 2) ? -1 : 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void mask_bbox_kernel(U8View m, int* bbox, long total_strips, int strips_per_row) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_strips) return;
+    const int sx = (int)(idx % strips_per_row);
+    long r = idx / strips_per_row;
+    const int y = (int)(r % m.h);
+    const int v = (int)(r / m.h);
+    const unsigned char* row = m.p + (long)v * m.sn + (long)y * m.sh;
+    int lo = 0x7fffffff, hi = -1;
+    const int x1 = min(m.w, (sx + 1) * 64);
+    for (int x = sx * 64; x < x1; ++x)
+        if (row[(long)x * m.sw]) { lo = min(lo, x); hi = x; }
+    if (hi < 0) return;
+    atomicMin(&bbox[v * 4 + 0], lo); atomicMax(&bbox[v * 4 + 2], hi);
+    atomicMin(&bbox[v * 4 + 1], y);  atomicMax(&bbox[v * 4 + 3], y);
+}
+__device__ __forceinline__ void square_axis(double c, double major, int size, int& lo, int& hi, int& pb, int& pa) {
+    pb = 0; pa = 0;
+    lo = (int)(c - major / 2.0);                                     // Python int(): truncation toward zero
+    if (lo < 0) { pb = -lo; lo = 0; }
+    hi = (int)(c + major / 2.0) + pb;
+    if (hi > size) { pa = hi - size; hi = size + pa; }
+}
+__global__ __launch_bounds__(64) void bbox_geom_kernel(const int* bbox, int* geom, int V, int H, int W) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const int x0 = bbox[v * 4], y0 = bbox[v * 4 + 1], x1 = bbox[v * 4 + 2], y1 = bbox[v * 4 + 3];
+    int* g = geom + v * 8;
+    if (x1 < 0) { for (int i = 0; i < 8; ++i) g[i] = 0; return; }
+    const int sxd = x1 - x0, syd = y1 - y0;
+    const double major = (double)max(sxd, syd) * 1.1;
+    const double cx = (double)x0 + (double)sxd / 2.0, cy = (double)y0 + (double)syd / 2.0;
+    int lx, hx, pxb, pxa, ly, hy, pyb, pya;
+    square_axis(cx, major, W, lx, hx, pxb, pxa);
+    square_axis(cy, major, H, ly, hy, pyb, pya);
+    g[0] = lx; g[1] = ly; g[2] = hx; g[3] = hy; g[4] = pxb; g[5] = pyb; g[6] = pxa; g[7] = pya;
+}
+
+// Heat-map argmax -> keypoints in frame pixels (trajectory_inference.py:76-79, 95-97; utils/keypoint_utils.py:66-92):
+// (x0 / hm_w) * crop_w + crop_x_min - pad_x in float64, stored as float32 (the pose fit's input type).
+__global__ __launch_bounds__(256) void keypoints_to_frame_kernel(const int* idx, const int* geom, float* out, int total, int nkp, int hm_w, int hm_h) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int v = i / nkp;
+    const int* g = geom + v * 8;
+    const int k = idx[i];
+    const double fx = (double)(k % hm_w) / (double)hm_w, fy = (double)(k / hm_w) / (double)hm_h;
+    out[2 * i] = (float)(fx * (double)(g[2] - g[0]) + (double)g[0] - (double)g[4]);
+    out[2 * i + 1] = (float)(fy * (double)(g[3] - g[1]) + (double)g[1] - (double)g[5]);
+}
+
 }  // namespace fusg
 
 using namespace fusg;
@@ -396,3 +546,87 @@ static int paste_back_u8_impl(const fusg_tensor* net, const fusg_tensor* masks, 
     return FUSG_OK;
 }
 extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) { return fusg::plan_dispatch(paste_back_u8_impl, stream, net, masks, geom, frame); }
+
+struct Norm3 { float m[3], s[3]; int has; };      // mode 1's mean / std, captured by value (host arrays at the ABI)
+static int crop_resize_impl(const fusg_tensor* src, const int32_t* geom, const fusg_tensor* dst, int32_t mode, Norm3 nm, void* stream) {
+    FUSG_CHECK(src && geom && dst && is_u8_hwc(*src, 3), "crop_resize_u8: u8 HWC source of 3 channels");
+    FUSG_CHECK(mode >= 0 && mode <= 2 && (src->n == 1 || src->n == dst->n) && dst->n >= 1 && dst->h >= 1 && dst->w >= 1, "crop_resize_u8: mode / batch");
+    CropIn a;
+    memset(&a, 0, sizeof(a));
+    a.src = u8view(*src); a.geom = geom; a.V = (int)dst->n; a.out_h = (int)dst->h; a.out_w = (int)dst->w; a.mode = mode;
+    a.src_per_v = src->n == 1 ? 0 : 1;
+    if (mode == 0) {
+        FUSG_CHECK(is_u8_hwc(*dst, 3) && dst->data != src->data, "crop_resize_u8: mode 0 needs a u8 HWC destination (not in place)");
+        a.dst8 = u8view(*dst);
+    } else {
+        FUSG_CHECK(is_nhwc(*dst) && dst->c == 3, "crop_resize_u8: modes 1 / 2 need an NHWC-physical f32 destination of 3 channels");
+        a.dstf = (float*)dst->data; a.dsn = dst->sn; a.dsh = dst->sh; a.dsw = dst->sw;
+        if (mode == 1) {
+            FUSG_CHECK(nm.has, "crop_resize_u8: mode 1 needs mean / std (host arrays of 3)");
+            for (int c = 0; c < 3; ++c) { a.mean[c] = nm.m[c]; a.stdv[c] = nm.s[c]; }
+        }
+    }
+    const long total = (long)a.V * a.out_h * a.out_w;
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, a, total);
+    FUSG_LAUNCH_CHECK("crop_resize_u8");
+    return FUSG_OK;
+}
+extern "C" int fusg_crop_resize_u8(const fusg_tensor* src, const int32_t* geom, const fusg_tensor* dst, int32_t mode, const float* mean3, const float* std3, void* stream) {
+    Norm3 nm = {{0, 0, 0}, {1, 1, 1}, (mean3 && std3) ? 1 : 0};
+    if (nm.has) for (int c = 0; c < 3; ++c) { nm.m[c] = mean3[c]; nm.s[c] = std3[c]; }
+    return fusg::plan_dispatch(crop_resize_impl, stream, src, geom, dst, mode, nm);
+}
+
+static int vunet_inputs_impl(const fusg_tensor* frame, const fusg_tensor* masks, const fusg_tensor* src_sketch, const fusg_tensor* dst_sketch,
+                             const int32_t* geom, const fusg_tensor* x, const fusg_tensor* y, void* stream) {
+    FUSG_CHECK(frame && masks && src_sketch && dst_sketch && geom && x && y && is_u8_hwc(*frame, 3) && frame->n == 1 &&
+               is_u8_hwc(*src_sketch, 3) && is_u8_hwc(*dst_sketch, 3), "vunet_inputs: u8 HWC frame [1] and sketches [V]");
+    FUSG_CHECK(masks->data && masks->dtype == FUSG_U8 && masks->c == 1 && masks->n == src_sketch->n && masks->h == frame->h && masks->w == frame->w &&
+               src_sketch->h == frame->h && src_sketch->w == frame->w && dst_sketch->n == masks->n && dst_sketch->h == frame->h && dst_sketch->w == frame->w,
+               "vunet_inputs: masks [V, 1, H, W] u8 and sketches of the frame's size");
+    FUSG_CHECK(is_nhwc(*x) && is_nhwc(*y) && x->c == 6 && y->c == 3 && x->n == masks->n && y->n == masks->n && x->h == y->h && x->w == y->w,
+               "vunet_inputs: x [V, 6, h, w] and y [V, 3, h, w] NHWC-physical f32");
+    VuIn a;
+    a.frame = u8view(*frame); a.ssk = u8view(*src_sketch); a.dsk = u8view(*dst_sketch);
+    a.mask = U8View{(unsigned char*)masks->data, masks->sn, masks->sh, masks->sw, (int)masks->n, (int)masks->h, (int)masks->w};
+    a.geom = geom; a.x = (float*)x->data; a.xsn = x->sn; a.xsh = x->sh; a.xsw = x->sw;
+    a.y = (float*)y->data; a.ysn = y->sn; a.ysh = y->sh; a.ysw = y->sw;
+    a.V = (int)masks->n; a.out_h = (int)x->h; a.out_w = (int)x->w;
+    const long total = (long)a.V * a.out_h * a.out_w;
+    hipLaunchKernelGGL(vunet_inputs_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, a, total);
+    FUSG_LAUNCH_CHECK("vunet_inputs");
+    return FUSG_OK;
+}
+extern "C" int fusg_vunet_inputs(const fusg_tensor* frame, const fusg_tensor* masks, const fusg_tensor* src_sketch, const fusg_tensor* dst_sketch,
+                                 const int32_t* geom, const fusg_tensor* x, const fusg_tensor* y, void* stream) {
+    return fusg::plan_dispatch(vunet_inputs_impl, stream, frame, masks, src_sketch, dst_sketch, geom, x, y);
+}
+
+static int mask_bbox_geom_impl(const fusg_tensor* masks, int32_t* bbox, int32_t* geom, void* stream) {
+    FUSG_CHECK(masks && bbox && geom && masks->data && masks->dtype == FUSG_U8 && masks->c == 1 && masks->n >= 1 && masks->h >= 1 && masks->w >= 1 &&
+               masks->h < 32768 && masks->w < 32768, "mask_bbox_geom: masks [V, 1, H, W] u8");
+    const int V = (int)masks->n;
+    U8View m{(unsigned char*)masks->data, masks->sn, masks->sh, masks->sw, V, (int)masks->h, (int)masks->w};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3((4 * V + 255) / 256), dim3(256), 0, s, bbox, 4 * V);
+    const int spr = (m.w + 63) / 64;
+    const long strips = (long)V * m.h * spr;
+    hipLaunchKernelGGL(mask_bbox_kernel, dim3(blocks2d(strips)), dim3(256), 0, s, m, bbox, strips, spr);
+    hipLaunchKernelGGL(bbox_geom_kernel, dim3((V + 63) / 64), dim3(64), 0, s, (const int*)bbox, geom, V, m.h, m.w);
+    FUSG_LAUNCH_CHECK("mask_bbox_geom");
+    return FUSG_OK;
+}
+extern "C" int fusg_mask_bbox_geom(const fusg_tensor* masks, int32_t* bbox, int32_t* geom, void* stream) {
+    return fusg::plan_dispatch(mask_bbox_geom_impl, stream, masks, bbox, geom);
+}
+
+static int keypoints_to_frame_impl(const int32_t* idx, const int32_t* geom, float* out, int32_t vehicles, int32_t nkp, int32_t hm_w, int32_t hm_h, void* stream) {
+    FUSG_CHECK(idx && geom && out && vehicles >= 1 && nkp >= 1 && hm_w >= 1 && hm_h >= 1, "keypoints_to_frame: arguments");
+    const int total = vehicles * nkp;
+    hipLaunchKernelGGL(keypoints_to_frame_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, geom, out, total, nkp, hm_w, hm_h);
+    FUSG_LAUNCH_CHECK("keypoints_to_frame");
+    return FUSG_OK;
+}
+extern "C" int fusg_keypoints_to_frame(const int32_t* idx, const int32_t* geom, float* out, int32_t vehicles, int32_t nkp, int32_t hm_w, int32_t hm_h, void* stream) {
+    return fusg::plan_dispatch(keypoints_to_frame_impl, stream, idx, geom, out, vehicles, nkp, hm_w, hm_h);
+}

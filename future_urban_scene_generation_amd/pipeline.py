@@ -156,7 +156,8 @@ class VehiclePipeline:
             nets += [self.edge, self.inp]
         for n in nets:
             n.to(self.device).eval()
-        self._nets = nets
+        # the FusedNets whose packed-weight caches a recorded pass points into (EdgeModel / InpaintingModel wrap theirs)
+        self._nets = [getattr(n, "generator", n) for n in nets]
         self._status = None                       # this pipeline's own range-status word (ops.status_scope), made on first use
 
     # The networks of one crop pass do not depend on each other (hourglass / ICN / VUnet; edge -> inpaint is one
@@ -336,6 +337,92 @@ class VehiclePipeline:
         # the ICN's big launches are issued first, on the caller's stream
         return self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)] + ([("inpaint", inpaint)] if self.inpaint else []))
 
+    # ------------------------------------------------------------------------------------------ per-frame chain
+    def run_frame(self, scene: Dict, check: Optional[str] = "sync") -> Dict:
+        """One frame's vehicles from detector boxes to the two composited frames, device-resident: the reference's
+        per-vehicle order (trajectory_inference.py:55-250, first frame) batched over the V vehicles of the frame:
+
+            box crop -> hourglass -> argmax -> keypoints in frame pixels -> pose fit (4 LM starts per vehicle)
+            plane warp (homographies fitted on the host) -> ICN inputs -> ICN -> to_image(from_LAB=True)
+            VUnet inputs -> VUnet first-frame -> to_image
+            resize-back + masked paste of every vehicle, in vehicle order (later vehicles overwrite earlier ones)
+
+        scene (see `synth_frame`): 'frame' uint8 [H, W, 3] (CUDA); 'bboxes' int [V, 4] (host: the detector's boxes);
+        'masks' uint8 [V, H, W] (CUDA, non-zero = vehicle: the rendered sketch mask, the reference's ~sketch_mask);
+        'src_sketch' / 'dst_sketch' uint8 [V, H, W, 3]; 'src_planes' uint8 [V, 5, H, W, 3]; 'src_kp' / 'dst_kp' host lists
+        [V][5] of int32 [n, 2] plane corner points; 'src_vis' / 'dst_vis' host [V, 5]; 'kp3d' float32 [V, 12, 3] (host: the
+        CAD model's keypoints); 'focals' / 'centers' [2] (host); optional 'background' uint8 [H, W, 3] (default: the frame).
+        What the reference computes BETWEEN the pose fit and the plane warp - rendering the posed CAD model into sketches,
+        masks and plane corner points with Open3D (warp_learn/vehicle_utils.py) - is out of scope: those
+        are inputs here, and the pose is an output for that renderer.
+
+        Returns 'kp_idx' int32 [V, 12], 'kp_xy' float32 [V, 12, 2], 'pose' = list of (error, rvec [3, 1], tvec [3, 1]),
+        'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8]."""
+        rng = torch.get_rng_state() if check == "sync" else None
+        out = self._guarded(self._run_frame, (scene,), check, rng)
+        # the reference's host epilogue of the pose fit (argmin over the four starts, sign flip): 4 x 7 numbers per vehicle
+        from .utils.pnp_utils import select_and_flip
+        rv, tv, er = (t.cpu().numpy() for t in out.pop("_pose_raw"))
+        out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
+        return out
+
+    @torch.no_grad()
+    def _run_frame(self, scene):
+        import numpy as np
+
+        from . import frame_ops as fo
+        from . import ops
+        from .utils.pnp_utils import cpc_fit_device
+        from .warp_learn import planes_utils as pu
+        dev = self.device
+        frame = scene["frame"]
+        H, W, _ = frame.shape
+        bboxes = np.asarray(scene["bboxes"]).reshape(-1, 4)
+        V, R = bboxes.shape[0], 256
+        self.vunet.set_vehicle_seeds(scene.get("vehicle_seeds"))
+        with torch.cuda.device(dev):
+            # ---- uint8 glue on the caller's stream
+            geom_box = fo.box_geometry((H, W), bboxes, dev)
+            img_bbox = fo.crop_resize(frame, geom_box, (R, R), 0)                              # :58-60
+            hg_x = fo.crop_resize(frame, geom_box, (R, R), 1, fo.IMAGENET_MEAN, fo.IMAGENET_STD)   # :61-65
+            central = fo.central_crop(img_bbox)                                                # vehicle_utils.py:49-52
+            jobs = [pu.warp_jobs(scene["src_kp"][v], scene["dst_kp"][v], scene["src_vis"][v], scene["dst_vis"][v])
+                    for v in range(V)]
+            warped = pu.warp_planes_batch(scene["src_planes"], jobs)                           # :171-175
+            _, geom = fo.mask_bbox_geom(scene["masks"])
+            icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], central, geom, R, R)     # :179-180
+            vu_x, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["src_sketch"], scene["dst_sketch"], geom, R)   # :203-228
+            f32 = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2)))).to(dev)   # noqa: E731
+            focals, centers = f32(scene["focals"]), f32(scene["centers"])
+            kp3d = torch.from_numpy(np.asarray(scene["kp3d"], np.float32)).to(dev)
+
+            def hg():
+                hm = self.hg(hg_x)["heatmaps"][-1]
+                idx = ops.argmax_hw(hm)                                                        # :75-79
+                kp = fo.keypoints_to_frame(idx, geom_box, tuple(hm.shape[-2:]))                # :95-97
+                rv, tv, er = cpc_fit_device(focals, centers, kp, kp3d)                         # :104-105
+                return {"kp_idx": idx, "kp_xy": kp, "_rv": rv, "_tv": tv, "_er": er}
+
+            def icn():
+                return {"icn_u8": pu.to_image_device(self.icn(icn_x), True)}                   # :182
+
+            def vunet():
+                vu = self.vunet
+                (do, ds), join = self._side("vunet_shape", lambda: vu.forward_dec_up(vu_y))
+                eo, es = vu.forward_enc_up(vu_x)
+                mu_app, _ = vu.forward_enc_down(eo, es)
+                join()
+                xt, _, _ = vu.forward_dec_down(do, ds, mu_app)                                 # :230-233
+                return {"vunet_u8": ops.to_image_u8(xt)}                                       # :234
+
+            out = self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)])
+            back = scene.get("background", frame)
+            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"])       # :184-198
+            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"])   # :236-250
+            out["geom"] = geom
+            out["_pose_raw"] = (out.pop("_rv"), out.pop("_tv"), out.pop("_er"))
+        return out
+
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
                  check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
         rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync") else None
@@ -484,3 +571,63 @@ def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int =
         e = synth_inputs("edge", batch, res, seed)
         b.update(ec_img=e["img"], ec_gray=e["gray"], ec_edge=e["edge"], ec_mask=e["mask"])
     return {k: t.to(device) for k, t in b.items()}
+
+
+def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 0) -> Dict:
+    """A synthetic frame for `VehiclePipeline.run_frame`: smooth random texture, `vehicles` detector boxes, and per
+    vehicle what the reference's renderer would hand over - an elliptical sketch (normal-map colours) with its mask,
+    five texture-plane quadrilaterals (corner points before and after a small pose change, visibilities) and the planes
+    cut out of the frame with them (`fusg_fill_poly_planes_u8`), plus 12 CAD keypoints and camera intrinsics.  All
+    pixel data lives on `device`; point lists and boxes are host arrays, as in the reference."""
+    import numpy as np
+
+    from .warp_learn import planes_utils as pu
+    H, W = frame_hw
+    g = np.random.default_rng(seed)
+    dev = torch.device(device)
+    tg = torch.Generator().manual_seed(seed)
+    low = torch.rand((1, 3, H // 16 + 2, W // 16 + 2), generator=tg)
+    tex = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)[0]
+    tex = (tex + 0.08 * torch.rand((3, H, W), generator=tg)).clamp(0, 1)
+    frame = (tex.permute(1, 2, 0) * 255).to(torch.uint8).contiguous().to(dev)
+    yy, xx = np.mgrid[0:H, 0:W]
+    bboxes, masks, sk_src, sk_dst, planes, src_kp, dst_kp, src_vis, dst_vis, kp3d = [], [], [], [], [], [], [], [], [], []
+    for v in range(vehicles):
+        bw, bh = int(g.integers(W // 8, W // 4)), int(g.integers(H // 6, H // 3))
+        x0 = int(g.integers(-bw // 6, W - bw + bw // 6))                       # some boxes run off the frame
+        y0 = int(g.integers(-bh // 6, H - bh + bh // 6))
+        bboxes.append([x0, y0, x0 + bw, y0 + bh])
+        cx, cy = x0 + bw / 2, y0 + bh / 2
+        ell = (((xx - cx) / (0.45 * bw)) ** 2 + ((yy - cy) / (0.42 * bh)) ** 2) <= 1.0
+        if not ell.any():
+            ell[min(max(int(cy), 0), H - 1), min(max(int(cx), 0), W - 1)] = True
+        m = ell.astype(np.uint8)
+        nrm = np.stack([(xx - cx) / (0.45 * bw), (yy - cy) / (0.42 * bh), np.ones_like(xx, dtype=np.float64) * 0.6], -1)
+        col = np.clip((nrm * 0.5 + 0.5) * 255, 1, 255).astype(np.uint8) * m[..., None]
+        masks.append(m)
+        sk_src.append(col)
+        sk_dst.append(np.ascontiguousarray(col[..., ::-1]) if v % 2 else col)
+        # five quadrilaterals / hexagons inside the box, and the same after a small perturbation
+        def poly(n, ox, oy, sx, sy):
+            ang = np.sort(g.uniform(0, 2 * np.pi, n))
+            return np.stack([cx + ox * bw + sx * bw * np.cos(ang), cy + oy * bh + sy * bh * np.sin(ang)], 1)
+        spec = [(6, -0.18, 0.0, 0.22, 0.3), (6, 0.18, 0.0, 0.22, 0.3), (4, 0.0, -0.2, 0.25, 0.15), (4, 0.0, 0.05, 0.2, 0.2),
+                (4, 0.0, 0.25, 0.25, 0.12)]
+        s_pts = [poly(*sp) for sp in spec]
+        d_pts = [p + g.normal(0, 0.02 * bw, p.shape) for p in s_pts]
+        src_kp.append([np.int32(p) for p in s_pts])
+        dst_kp.append([np.int32(p) for p in d_pts])
+        vis = g.integers(0, 2, 5).astype(np.uint8)
+        vis[2] = 1
+        src_vis.append(vis)
+        dv = vis.copy()
+        if v % 3 == 1:                                                        # exercise the left/right symmetry swap
+            dv[0], dv[1] = 0, 1
+        dst_vis.append(dv)
+        planes.append(pu.fill_planes(frame, src_kp[-1]))
+        kp3d.append((g.uniform(-1, 1, (12, 3)) * np.array([0.9, 0.5, 2.0]) * 5).astype(np.float32))
+    t8 = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)   # noqa: E731
+    return {"frame": frame, "bboxes": np.asarray(bboxes, dtype=np.int64), "masks": t8(masks), "src_sketch": t8(sk_src),
+            "dst_sketch": t8(sk_dst), "src_planes": torch.stack(planes), "src_kp": src_kp, "dst_kp": dst_kp,
+            "src_vis": np.stack(src_vis), "dst_vis": np.stack(dst_vis), "kp3d": np.stack(kp3d),
+            "focals": np.array([1.1 * W, 1.1 * W], np.float32), "centers": np.array([W / 2, H / 2], np.float32)}

@@ -214,16 +214,13 @@ def warp_perspective(src: torch.Tensor, H: Sequence[np.ndarray], dsize: Tuple[in
     return out
 
 
-def warp_unwarp_planes(src_planes: Image, src_planes_kpoints: List[np.ndarray], dst_planes_kpoints: List[np.ndarray],
-                       src_visibilities, dst_visibilities, pascal_class: str, pascal_texture_planes=pascal_texture_planes,
-                       unwarp: bool = True):
-    """Reference signature (planes_utils.py:40-82): visibility / symmetry gating and the homography fits on the host,
-    both warps of all selected planes in two batched launches.  `unwarp=False` skips the second warp (its result is
-    discarded by the reference's only caller, trajectory_inference.py:171) and returns None for it."""
-    planes, as_np = _to_dev(src_planes)
-    keys = list(pascal_texture_planes[pascal_class].keys())
+def warp_jobs(src_planes_kpoints, dst_planes_kpoints, src_visibilities, dst_visibilities, pascal_class: str = "car",
+              texture_planes=None):
+    """The host half of warp_unwarp_planes (planes_utils.py:53-75): which planes are warped where, and their two
+    homographies.  -> list of (source plane i, destination slot j, H12, H21)."""
+    keys = list((texture_planes or pascal_texture_planes)[pascal_class].keys())
     sym = [keys.index("left"), keys.index("right")]
-    jobs = []                                                   # (source plane i, destination slot j, H12, H21)
+    jobs = []
     for i in range(len(keys)):
         if not src_visibilities[i]:
             continue
@@ -238,6 +235,40 @@ def warp_unwarp_planes(src_planes: Image, src_planes_kpoints: List[np.ndarray], 
         H21 = find_homography(dst_planes_kpoints[j], src_planes_kpoints[i])
         if H12 is not None and H21 is not None:
             jobs.append((i, j, H12, H21))
+    return jobs
+
+
+def warp_planes_batch(src_planes: torch.Tensor, jobs_per_vehicle) -> torch.Tensor:
+    """`planes_warped` of warp_unwarp_planes for every vehicle of a frame in ONE launch: src_planes CUDA uint8
+    [V, P, H, W, 3], jobs_per_vehicle[v] = warp_jobs(...) of vehicle v -> [V, P, H, W, 3] (zeros where nothing is warped)."""
+    V, P, H, W, _ = src_planes.shape
+    flat = src_planes.reshape(V * P, H, W, 3)
+    warped = torch.zeros_like(flat)
+    src_idx, dst_idx, Hs = [], [], []
+    for v, jobs in enumerate(jobs_per_vehicle):
+        last = {}
+        for k, (i, j, H12, _) in enumerate(jobs):                 # plane order: a later job on slot j overwrites an earlier one
+            last[j] = (i, H12)
+        for j, (i, H12) in last.items():
+            src_idx.append(v * P + i)
+            dst_idx.append(v * P + j)
+            Hs.append(H12)
+    if Hs:
+        si = torch.tensor(src_idx, device=flat.device)
+        w1 = warp_perspective(flat[si], Hs, (W, H))
+        warped[torch.tensor(dst_idx, device=flat.device)] = w1
+    return warped.view(V, P, H, W, 3)
+
+
+def warp_unwarp_planes(src_planes: Image, src_planes_kpoints: List[np.ndarray], dst_planes_kpoints: List[np.ndarray],
+                       src_visibilities, dst_visibilities, pascal_class: str, pascal_texture_planes=pascal_texture_planes,
+                       unwarp: bool = True):
+    """Reference signature (planes_utils.py:40-82): visibility / symmetry gating and the homography fits on the host,
+    both warps of all selected planes in two batched launches.  `unwarp=False` skips the second warp (its result is
+    discarded by the reference's only caller, trajectory_inference.py:171) and returns None for it."""
+    planes, as_np = _to_dev(src_planes)
+    jobs = warp_jobs(src_planes_kpoints, dst_planes_kpoints, src_visibilities, dst_visibilities, pascal_class,
+                     pascal_texture_planes)
     warped = torch.zeros_like(planes)
     unwarped = torch.zeros_like(planes) if unwarp else None
     if jobs:
@@ -275,6 +306,18 @@ def icn_inputs_batch(planes: torch.Tensor, sketches: torch.Tensor, centrals: tor
                                         C.byref(_u8desc(planes.reshape(B * P, H, W, 3).contiguous())), geom_d.data_ptr(),
                                         C.byref(ops.desc(out)), ops.stream_ptr()), "icn_inputs")
     return out, infos
+
+
+def icn_inputs_device(planes: torch.Tensor, sketches: torch.Tensor, centrals: torch.Tensor, geom: torch.Tensor,
+                      icn_w: int = 256, icn_h: int = 256) -> torch.Tensor:
+    """icn_inputs_batch with the crop geometry already on the device (frame_ops.mask_bbox_geom): nothing is read back."""
+    B, P, H, W, _ = planes.shape
+    out = ops.nhwc_empty(B, 3 * (P + 2), icn_h, icn_w, planes.device, zero=True)
+    with torch.cuda.device(planes.device):
+        L.check(L.lib().fusg_icn_inputs(C.byref(_u8desc(sketches.contiguous())), C.byref(_u8desc(centrals.contiguous())),
+                                        C.byref(_u8desc(planes.reshape(B * P, H, W, 3).contiguous())), geom.data_ptr(),
+                                        C.byref(ops.desc(out)), ops.stream_ptr()), "icn_inputs")
+    return out
 
 
 def get_icn_inputs(planes: Image, sketch_normal: Image, sketch_mask, central_crop: Image, icn_w: int, icn_h: int):
@@ -331,6 +374,16 @@ def to_image_device(x: torch.Tensor, from_LAB: bool) -> torch.Tensor:
     """[B, 3, H, W] float32 in [-1, 1] (CUDA) -> uint8 [B, H, W, 3]: trunc(clip((x + 1) / 2 * 255)) [+ Lab -> BGR]."""
     u8 = ops.to_image_u8(x.to(torch.float32))
     return lab2bgr(u8) if from_LAB else u8
+
+
+def paste_back_device(frame: torch.Tensor, net_images: torch.Tensor, geom: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+    """paste_back with device geometry rows (int32 [V, 8]) and device masks (uint8 [V, H, W]); returns a new frame tensor."""
+    fr = frame.contiguous().clone()
+    V, H, W = masks.shape
+    with torch.cuda.device(fr.device):
+        L.check(L.lib().fusg_paste_back_u8(C.byref(_u8desc(net_images.contiguous())), C.byref(ops.desc(masks.contiguous().view(V, 1, H, W))),
+                                           geom.data_ptr(), C.byref(_u8desc(fr[None])), ops.stream_ptr()), "paste_back_u8")
+    return fr
 
 
 def paste_back(frame: Image, net_images: torch.Tensor, crop_infos: Sequence[dict], paste_masks: Image) -> Image:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 106
+#define FUSG_VERSION 107
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -360,6 +360,35 @@ int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream
  * vehicle's image resized (cv2.resize INTER_LINEAR) to its crop, padding removed, placed at crop_xy_min - or 0 where
  * the pixel lies outside that rectangle; masks u8 [V, 1, H, W] (non-zero = paste), geom as in fusg_icn_inputs. */
 int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream);
+
+/* ---- frame-chain glue (pipeline.VehiclePipeline.run_frame): the uint8 -> float steps between the frame and the networks */
+/* square_crop_from_bbox (utils/crop_utils.py:4-52) + cv2.resize INTER_LINEAR for V windows: src u8 HWC [1] (every
+ * window cut from the same image: the frame, trajectory_inference.py:58-60) or [V] (one image per window: the central
+ * crop of each vehicle's resized box, warp_learn/vehicle_utils.py:49-52); geom = DEVICE int32 [V][8] as in fusg_icn_inputs;
+ * dst [V, 3, h, w].  mode 0: u8 HWC.  mode 1: f32 NHWC-physical, transforms.ToTensor + normalize: (v / 255 - mean[c]) /
+ * std[c] (trajectory_inference.py:61-64; mean3 / std3 = HOST arrays of 3 floats, read before return).  mode 2: f32
+ * NHWC-physical, to_tensor: v / 255 * 2 - 1 (utils/misc_utils.py:35-49).  A window of zero extent writes zeros. */
+int fusg_crop_resize_u8(const fusg_tensor* src, const int32_t* geom, const fusg_tensor* dst, int32_t mode,
+                        const float* mean3, const float* std3, void* stream);
+/* The VUnet's first-frame inputs (trajectory_inference.py:203-228) for V vehicles: frame u8 HWC [1, 3, H, W]; masks u8
+ * [V, 1, H, W] (non-zero = vehicle: the reference's ~src_sketch_mask); src_sketch / dst_sketch u8 HWC [V, 3, H, W];
+ * geom = DEVICE int32 [V][8], the square window of each mask's bounding box (fusg_mask_bbox_geom).  Writes
+ * x [V, 6, h, w] = cat[to_tensor(resize(crop(frame * mask))), to_tensor(resize(crop(src_sketch))[..., ::-1])] with
+ * masked-frame pixels set to 255 where the resized src sketch is all zero, and y [V, 3, h, w] =
+ * to_tensor(resize(crop(dst_sketch))[..., ::-1]); both f32 NHWC-physical. */
+int fusg_vunet_inputs(const fusg_tensor* frame, const fusg_tensor* masks, const fusg_tensor* src_sketch,
+                      const fusg_tensor* dst_sketch, const int32_t* geom, const fusg_tensor* x, const fusg_tensor* y, void* stream);
+/* np.nonzero(mask) -> (x_min, y_min, x_max, y_max) (warp_learn/models.py:333-336; trajectory_inference.py:204-206) and
+ * the square_crop_from_bbox geometry of that box (utils/crop_utils.py:13-50, Python's float arithmetic in double) for V
+ * masks u8 [V, 1, H, W], entirely on the device: bbox = DEVICE int32 [V][4], geom = DEVICE int32 [V][8].  An empty mask
+ * gives an all-zero geom row (the reference raises there and skips the vehicle). */
+int fusg_mask_bbox_geom(const fusg_tensor* masks, int32_t* bbox, int32_t* geom, void* stream);
+/* Heat-map argmax indices -> keypoints in frame pixels (utils/keypoint_utils.py:66-92 after F.interpolate to 256 =
+ * (x0 / hm_w, y0 / hm_h); trajectory_inference.py:95-97: * crop side + crop_min - pad, in float64), stored float32
+ * [V][nkp][2] - the pose fit's input.  idx = DEVICE int32 [V][nkp] (fusg_argmax_hw), geom as above (the detector
+ * box's crop). */
+int fusg_keypoints_to_frame(const int32_t* idx, const int32_t* geom, float* out, int32_t vehicles, int32_t nkp,
+                            int32_t hm_w, int32_t hm_h, void* stream);
 
 /* ---- pose fit ------------------------------------------------------------------------------- */
 /*

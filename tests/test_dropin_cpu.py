@@ -57,3 +57,29 @@ def test_reference_import_lines_resolve_to_the_dropins(tmp_path):
     assert out["utils_siblings"] == ["reference utils.crop_utils", "reference utils.geometry"]
     assert out["siblings"] == ["reference warp_learn.planes_utils", "reference warp_learn.online_visibility",
                                "reference edgeconnect.config", "reference edgeconnect.utils", "reference vunet.data_utils"]
+
+
+def test_planes_utils_shim_is_opt_in(tmp_path):
+    """`from warp_learn.planes_utils import to_image, warp_unwarp_planes` (trajectory_inference.py:28-29): by default the
+    shim executes the reference checkout's own file; FUSG_DROPIN_PLANES_UTILS=1 (or install(planes_utils=True)) selects
+    the device versions."""
+    ref = tmp_path / "reference" / "warp_learn"
+    ref.mkdir(parents=True)
+    (ref / "__init__.py").write_text("")
+    (ref / "planes_utils.py").write_text("def to_image(x, from_LAB):\n    return 'reference'\n\ndef warp_unwarp_planes(*a):\n    return 'reference'\n")
+    code = "from warp_learn.planes_utils import to_image, warp_unwarp_planes; import warp_learn.planes_utils as m; print('RESULT', m.FUSG_DROPIN, to_image.__module__, to_image(0, False) if not m.FUSG_DROPIN else '-')"
+    base = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(REPO, "dropin"), REPO, str(tmp_path / "reference")]))
+    base.pop("FUSG_DROPIN_PLANES_UTILS", None)
+    r = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT False warp_learn.planes_utils reference" in r.stdout
+    r = subprocess.run([sys.executable, "-c", code], env=dict(base, FUSG_DROPIN_PLANES_UTILS="1"), capture_output=True, text=True,
+                       timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True future_urban_scene_generation_amd.warp_learn.planes_utils" in r.stdout
+    code2 = ("import sys, future_urban_scene_generation_amd as f; f.install(); print('A', 'warp_learn.planes_utils' in sys.modules); "
+             "f.install(planes_utils=True); import warp_learn.planes_utils as m; print('B', m.__name__)")
+    r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, str(tmp_path / "reference")])),
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "A False" in r.stdout and "B future_urban_scene_generation_amd.warp_learn.planes_utils" in r.stdout
