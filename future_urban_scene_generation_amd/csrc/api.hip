@@ -37,6 +37,7 @@ const EnvSwitches& env_switches() {
         EnvSwitches s;
         s.no_vec_epi = getenv("FUSG_NO_VEC_EPI") != nullptr;
         s.no_halo = getenv("FUSG_NO_HALO") != nullptr;
+        s.no_touch = getenv("FUSG_NO_TOUCH") != nullptr;          // no L2 warm-up of the weights (conv_kernel.h, l2_touch)
         s.halo_minwg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
         s.halo_bn = getenv("FUSG_HALO_BN") ? atoi(getenv("FUSG_HALO_BN")) : 0;
         return s;

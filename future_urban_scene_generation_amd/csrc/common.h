@@ -55,8 +55,8 @@ static inline bool same_shape(const fusg_tensor& a, const fusg_tensor& b) {
 hipError_t ensure_dyn_lds(const void* fn, int bytes);
 
 // Development switches, read from the environment ONCE (first use): FUSG_NO_VEC_EPI, FUSG_NO_HALO,
-// FUSG_HALO_MINWG, FUSG_HALO_BN (tools/README.md).  (api.hip)
-struct EnvSwitches { bool no_vec_epi, no_halo; long halo_minwg; int halo_bn; };
+// FUSG_HALO_MINWG, FUSG_HALO_BN, FUSG_NO_TOUCH (tools/README.md).  (api.hip)
+struct EnvSwitches { bool no_vec_epi, no_halo, no_touch; long halo_minwg; int halo_bn; };
 const EnvSwitches& env_switches();
 
 // ---- recorded passes (plan.hip) ----------------------------------------------------------------------------------

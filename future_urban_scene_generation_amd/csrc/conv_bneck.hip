@@ -35,6 +35,7 @@ struct BneckK {
     const float* zeros;
     int* status;
     int B, H, W, Cin, tiles_x, tiles_y;
+    int touch_w;                          // 1: the first workgroups warm L2 with the block's three weight panels (l2_touch)
 };
 
 constexpr int BN_HP = 100;                // 10 x 10 halo pixels
@@ -75,6 +76,18 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     const int oy0 = ty * 8, ox0 = tx * 8;
     float amax = 0.f;
     const float ninf = -__builtin_inff();
+
+    if (k.touch_w && blockIdx.x < TOUCH_FIRST_WGS / 2) {
+        // Inside the pass every block meets its ~850 KiB of weights cold, and the loops below fetch them two steps
+        // ahead: on the 4 x 4 .. 16 x 16 levels (32 - 128 workgroups) that is an HBM round trip per step, 48 steps in
+        // a row (31 us with warm weights, 52 us in the pass).  One dword per 128-byte line of all three panels now:
+        // conv1's first (needed at once), then conv2's, then conv3's.
+        void* dummy = (char*)smem_h + bneck_lds(P);
+        const long n1 = (long)(k.Cin >> 5) * NCH * 4096, n2 = (long)9 * NCH * NCH * 4096, n3 = (long)NCH * 2 * NCH * 4096;   // bytes
+        for (long o = (long)t * 128; o < n1; o += 256 * 128) l2_touch((const char*)k.w1 + o, dummy);
+        for (long o = (long)t * 128; o < n2; o += 256 * 128) l2_touch((const char*)k.w2 + o, dummy);
+        for (long o = (long)t * 128; o < n3; o += 256 * 128) l2_touch((const char*)k.w3 + o, dummy);
+    }
 
     // ------------------------------------------------------------------ conv1 on the halo
     const int kc = t & 7;
@@ -366,7 +379,8 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     const long wgs = (long)k.B * k.tiles_x * k.tiles_y;
     FUSG_CHECK(wgs < (1L << 31), "hg_bottleneck: grid");
     const void* fn = P == 128 ? (const void*)hg_bneck_h3<128> : (const void*)hg_bneck_h3<64>;
-    const size_t lds = bneck_lds(P);
+    const size_t lds = bneck_lds(P) + TOUCH_LDS_BYTES;
+    k.touch_w = env_switches().no_touch ? 0 : 1;
     if (hipError_t e = ensure_dyn_lds(fn, (int)lds); e != hipSuccess) { set_error("hg_bottleneck: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
     const double M = (double)x.n * x.h * x.w;
     prof_begin(0, s, 2.0 * M * ((double)x.c * P + 9.0 * P * P + 2.0 * P * P));   // the three convs' own FLOPs (no halo recompute)

@@ -15,11 +15,28 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK p, int nph
     const long pm = idx / n4;
     const int m = (int)(pm % p.M);
     const int phase = (int)(pm / p.M);
+    // slabs are summed in slab order (the result does not depend on the unrolling); eight independent 16-byte loads are
+    // in flight per thread instead of one load per dependent add (the loop used to pay one L2 round trip per slab)
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.ksplit; ++k) {
-        const f32x4 v = *(const f32x4*)(p.ws + ((long)(phase * p.ksplit + k) * p.M + m) * p.Cout_pad + c4 * 4);
-        s += v;
+    const float* base = p.ws + ((long)phase * p.ksplit * p.M + m) * p.Cout_pad + c4 * 4;
+    const long slab = (long)p.M * p.Cout_pad;
+    int k = 0;
+    for (; k + 8 <= p.ksplit; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(base + (long)(k + j) * slab);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
     }
+    if (k + 4 <= p.ksplit) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(base + (long)(k + j) * slab);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
+        k += 4;
+    }
+    for (; k < p.ksplit; ++k) s += *(const f32x4*)(base + (long)k * slab);
     PixOff po;
     if (!pix_offsets(p, phase, m, po)) return;
 #pragma unroll
@@ -199,6 +216,7 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     k.qy0 = d->q_oy; k.qx0 = d->q_ox;
     k.zeros = zero_line();
     if (!k.zeros) { set_error("conv2d: cannot allocate the zero line"); return FUSG_ERR_LAUNCH; }
+    k.touch_w = env_switches().no_touch ? 0 : 1;
     k.wpack_h = (const _Float16*)d->wpack_h;
     if (d->precision == FUSG_PREC_F16X3) { k.wscale = d->wscale; k.status = d->status; }
     k.round_bits = d->precision == FUSG_PREC_EMU_BF16 ? 8 : (d->precision == FUSG_PREC_EMU_BF16X2 ? 16 : 0);

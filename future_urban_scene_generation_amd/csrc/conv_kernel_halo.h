@@ -67,6 +67,7 @@ struct HaloK {
     int qwoff[4];               // first weight slab of each quadrant (slabs of a quadrant are consecutive)
     int qtdy[4][4], qtdx[4][4]; // halo pixel offset (rows, columns) of each (quadrant, local tap)
     int nt32;                   // cout_pad / 32
+    int touch_off;              // byte offset of the L2-touch dummy region in dynamic LDS (conv_kernel.h, l2_touch)
 };
 
 __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, int ox, PixOff& o) {
@@ -174,6 +175,22 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const int nch32 = (p.C0 + hk.c1k) >> 5;
     const int ntaps = hk.kh * hk.kw;
     auto taps_of = [&](int cg) { return hk.s2d ? hk.qtaps[cg / nchq] : ntaps; };
+
+    if (p.touch_w && blockIdx.x < TOUCH_FIRST_WGS) {
+        // this wave column's weight slabs: TN * FPT KiB contiguous per (tap, chunk) slab, nslabs slabs wstep apart;
+        // the WM waves that share the column take every WM-th group of 64 lines
+        constexpr int LPS = TN * FPT * 8;                         // 128-byte lines per slab
+        const int nslabs = ntaps * nch32;                         // (quadrant form: the quadrants' taps add up to kh * kw)
+        void* dummy = (char*)smem_h + hk.touch_off;
+        const _Float16* wcol = hk.wfrag + (long)(nt * (BN / 32) + wn * TN) * FPT * 64 * 8;
+        for (int L0 = wm * 64; L0 < nslabs * LPS; L0 += WM * 64) {
+            const int L = L0 + lane;
+            if (L < nslabs * LPS) {
+                const int sl = L / LPS, q = L - sl * LPS;
+                l2_touch(wcol + (long)sl * wstep + q * 64, dummy);
+            }
+        }
+    }
 
     f32x4 hreg[NI];
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -368,6 +385,8 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
+    const int touch_off = (int)lds;
+    lds += TOUCH_LDS_BYTES;
     const int ni = (HP * 8 + 255) / 256;
     if (!halo_fits(k.HH, k.HW)) return hipErrorInvalidValue;
     const void* fn = nullptr;
@@ -381,9 +400,10 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
         if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 0) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 0) } else { FUSG_PICK_NI(PK_AFFINE, 0) }
     }
 #undef FUSG_PICK_NI
-    if (hipError_t e = ensure_dyn_lds(fn, 96 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dyn_lds(fn, 96 * 1024 + TOUCH_LDS_BYTES); e != hipSuccess) return e;
     HaloK kk = k;
     kk.RP = halo_row_pitch(k.HW);
+    kk.touch_off = touch_off;
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
