@@ -440,12 +440,15 @@ def main():
             executed = launched_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
             traffic, tsrc = None, None
             tpath = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
-            if prec == "f16x3" and not args.inpaint and args.res == 256 and os.path.exists(tpath):
+            leg_key = "%s_%d%s" % (prec, args.res, "_inpaint" if args.inpaint else "")
+            if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get("conv_bytes_per_launch")
-                    tsrc = "NOT measured in this run (PMC counters need their own rocprofv3 pass): %s, collected %s" % (
-                        "profiles/hbm_traffic_latest.json", tj.get("collected", "in an earlier run"))
+                    tj = tj.get("legs", {}).get(leg_key) or (tj if leg_key == "f16x3_256" else None)
+                    if tj:
+                        traffic = tj.get("conv_bytes_per_launch")
+                        tsrc = "NOT measured in this run (PMC counters need their own rocprofv3 pass): %s [%s], collected %s" % (
+                            "profiles/hbm_traffic_latest.json", leg_key, tj.get("collected", "in an earlier run"))
                 except (OSError, ValueError):
                     traffic = None
             if prec == "f32":

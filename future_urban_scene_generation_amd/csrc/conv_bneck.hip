@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     float amax = 0.f;
     const float ninf = -__builtin_inff();
 
-    if (k.touch_w && blockIdx.x < TOUCH_FIRST_WGS / 2) {
+    if (k.touch_w && gridDim.x <= TOUCH_MAX_WGS / 2) {
         // Inside the pass every block meets its ~850 KiB of weights cold, and the loops below fetch them two steps
-        // ahead: on the 4 x 4 .. 16 x 16 levels (32 - 128 workgroups) that is an HBM round trip per step, 48 steps in
-        // a row (31 us with warm weights, 52 us in the pass).  One dword per 128-byte line of all three panels now:
-        // conv1's first (needed at once), then conv2's, then conv3's.
+        // ahead: on the 4 x 4 .. 16 x 16 levels (32 - 128 workgroups) that is a memory round trip per step, 48 steps in
+        // a row.  One dword per 128-byte line of all three panels now: conv1's first (needed at once), then conv2's,
+        // then conv3's (conv_kernel.h, l2_touch: what it bought, and why larger grids do not do it).
         void* dummy = (char*)smem_h + bneck_lds(P);
         const long n1 = (long)(k.Cin >> 5) * NCH * 4096, n2 = (long)9 * NCH * NCH * 4096, n3 = (long)NCH * 2 * NCH * 4096;   // bytes
         for (long o = (long)t * 128; o < n1; o += 256 * 128) l2_touch((const char*)k.w1 + o, dummy);

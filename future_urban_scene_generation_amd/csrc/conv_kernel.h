@@ -62,7 +62,7 @@ struct ConvK {
                              // (8 = bf16, 16 = two bf16 pieces) - the numerics of a reduced-precision MFMA path emulated
                              // on the fp32 matrix cores (products of such operands are exact in fp32), for the bf16
                              // evidence of DESIGN.md / tests::test_reduced_precision_evidence; not a production path
-    int touch_w;             // 1: the first TOUCH_FIRST_WGS workgroups warm L2 with their weight range (l2_touch)
+    int touch_w;             // 1: a grid of at most TOUCH_MAX_WGS workgroups warms L2 with its weight ranges (l2_touch)
     const float* zeros;      // 256 B of zeros in device memory: where the gather of a zero-padded pixel reads.  It
                              // comes in through the kernel arguments so that the selected pointer stays a GLOBAL
                              // one (a select against the address of a __device__ variable degrades the load to
@@ -75,17 +75,20 @@ enum { PK_NONE = 0, PK_ELU = 1, PK_AFFINE = 2 };   // compile-time pre-op kind
 // of LDS that nothing reads - no VGPR destination, so nothing has to stay live while the line travels.  Why: inside
 // the pass every small layer meets its weights cold (each layer has its own, and ~35 GB of activations go through the
 // caches between two uses), and the kernels fetch weight fragments only one or two K-steps ahead of their use - so a
-// workgroup of a launch with few workgroups pays a full HBM / Infinity-Cache round trip PER K-STEP (measured: hourglass
-// 3x3 128->128 at 16 x 16: 23 us with warm weights, 46 us inside the pass).  Touching the workgroup's whole weight
-// range once at kernel start turns ~36 dependent misses into one.  Only the first workgroups of a grid do it
-// (`touch_wanted`): later ones find the lines in L2.
+// workgroup of a launch with few workgroups pays a memory round trip PER K-STEP.  Touching the workgroup's whole weight
+// range once at kernel start turns ~36 dependent misses into one.  Measured on the pass (round 3, rocprofv3 kernel traces
+// with and without it; the card of the "with" trace was ~5 % slower on large kernels): launches of <= 256 workgroups 7-15 %
+// shorter (halo kernel at 16 x 16: 32.7 -> 29.9 us; fused Bottleneck at 4 x 4 .. 16 x 16: 43 -> 41 us); launches of 512+
+// workgroups 5-12 % LONGER (whole pass, same card, FUSG_NO_TOUCH A/B with every grid touching: conv 25.1 -> 25.55 ms) (the lines are in L2 after
+// the first workgroups, and the compiler drains every LDS-DMA before the first staged chunk is used), the generic
+// gather 9-22 % longer at every size - so only small halo / Bottleneck grids do it (TOUCH_MAX_WGS).
 typedef __attribute__((address_space(1))) const void fusg_gptr;
 typedef __attribute__((address_space(3))) void fusg_lptr;
 __device__ __forceinline__ void l2_touch(const void* g, void* lds_dummy) {
     __builtin_amdgcn_global_load_lds((fusg_gptr*)g, (fusg_lptr*)lds_dummy, 4, 0, 0);
 }
 constexpr int TOUCH_LDS_BYTES = 256;               // the dummy region: 64 lanes x 4 bytes
-constexpr int TOUCH_FIRST_WGS = 1024;              // workgroups (in dispatch order) that warm L2: about the first round
+constexpr int TOUCH_MAX_WGS = 256;                 // grids up to this many workgroups warm L2 (see above)
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {

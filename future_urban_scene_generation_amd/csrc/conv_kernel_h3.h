@@ -158,17 +158,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
         bpiece[j] = q & 3;
     }
 
-    if (p.touch_w && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < TOUCH_FIRST_WGS) {
-        // this workgroup's weight range: rows nt*BN .. +BN of the hi and the lo panel, k of its K-split (conv_kernel.h)
-        const int s0 = ks * p.steps_per_split, s1 = min(p.nk, s0 + p.steps_per_split);
-        const int lines = ((s1 - s0) * BK * 2 + 127) >> 7;          // 128-byte lines per row segment
-        void* dummy = (char*)smem_h + (size_t)2 * 2 * (BM + BN) * LDH * sizeof(_Float16);
-        for (int r = t; r < 2 * BN; r += 256) {
-            const _Float16* row = (r < BN ? wh + (long)r * p.K_pad : wl + (long)(r - BN) * p.K_pad) + s0 * BK;
-            for (int i = 0; i < lines; ++i) l2_touch(row + i * 64, dummy);
-        }
-    }
-
     const float vfloor = (PK != PK_ELU && p.pre_relu) ? 0.f : -__builtin_inff();
     float amax = 0.f;
     struct Stage {
@@ -435,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
 template <int TM, int TN, int WM, int WN>
 hipError_t launch_h3(const ConvK& k, dim3 grid, hipStream_t s, int pk, bool gen) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    const size_t lds = (size_t)2 * 2 * (BM + BN) * LDH * sizeof(_Float16) + TOUCH_LDS_BYTES;      // + the l2_touch dummy
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * LDH * sizeof(_Float16);
     const void* fn = nullptr;
 #define FUSG_PICK(PKV, GENV) fn = (const void*)conv_igemm_h3<TM, TN, WM, WN, PKV, GENV>
     if (pk == PK_NONE) { if (gen) FUSG_PICK(PK_NONE, true); else FUSG_PICK(PK_NONE, false); }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const int ntaps = hk.kh * hk.kw;
     auto taps_of = [&](int cg) { return hk.s2d ? hk.qtaps[cg / nchq] : ntaps; };
 
-    if (p.touch_w && blockIdx.x < TOUCH_FIRST_WGS) {
+    if (p.touch_w && gridDim.x <= TOUCH_MAX_WGS) {
         // this wave column's weight slabs: TN * FPT KiB contiguous per (tap, chunk) slab, nslabs slabs wstep apart;
         // the WM waves that share the column take every WM-th group of 64 lines
         constexpr int LPS = TN * FPT * 8;                         // 128-byte lines per slab
@@ -192,10 +192,20 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     }
 
-    f32x4 hreg[NI];
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    // Staging registers of one chunk's halo.  Narrow tiles (FUSG_HALO_PD2 builds, TM * TN <= 2: the VUnet's 32 / 64-column
+    // layers) keep TWO sets and fetch two chunks ahead: a chunk's nine taps take ~0.8 us on a 32-column tile, less than
+    // one HBM round trip under load, so with one chunk in flight the workgroup waits for memory at every chunk boundary.
+    struct HSet { f32x4 r[NI]; f32x4 sc, sh; };
+#ifdef FUSG_HALO_PD2
+    constexpr bool PD2 = TM * TN <= 2;
+#else
+    constexpr bool PD2 = false;
+#endif
+    HSet hA, hB;
+    hA.sc = hB.sc = f32x4{1.f, 1.f, 1.f, 1.f};
+    hA.sh = hB.sh = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto halo_issue = [&](int cg) {
+    auto halo_issue = [&](HSet& S, int cg) {
         const bool s1 = cg >= nch0;
         const float* base = s1 ? p.src1 : p.src0;
         const int Cs = s1 ? p.Cs1 : p.Cs0;
@@ -204,27 +214,27 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         if (hk.s2d) { const int q = cg / nchq; coff = (cg - q * nchq) * CH + kc * 4; qpix += (q >> 1) * p.W + (q & 1); }
         if (PK == PK_AFFINE) {
             const long o = (long)b * p.pre_bstride + (s1 ? p.C0 : 0) + coff;
-            sc = *(const f32x4*)(p.pre_scale + o);
-            sh = *(const f32x4*)(p.pre_shift + o);
+            S.sc = *(const f32x4*)(p.pre_scale + o);
+            S.sh = *(const f32x4*)(p.pre_shift + o);
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float* ptr = base + (qpix + hpix[j]) * Cs + coff;
             if (PK != PK_AFFINE) ptr = ((hvalid >> j) & 1u) ? ptr : p.zeros;
-            hreg[j] = *(const f32x4*)ptr;
+            S.r[j] = *(const f32x4*)ptr;
         }
     };
-    auto halo_commit = [&]() {
+    auto halo_commit = [&](const HSet& S) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            f32x4 v = hreg[j];
+            f32x4 v = S.r[j];
             if (PK == PK_ELU) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
             } else if (PK == PK_AFFINE) {
                 const bool ok = (hvalid >> j) & 1u;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
+                for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], S.sc[c], S.sh[c]); v[c] = ok ? y : 0.f; }
             }
             if constexpr (BF) {
 #pragma unroll
@@ -311,15 +321,23 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     };
 
-    // ---- prologue: halo of chunk 0 and the first weight fragments
-    halo_issue(0);
+    // ---- prologue: halo of chunk 0 (and 1) and the first weight fragments
+    halo_issue(hA, 0);
+    if (PD2 && nch > 1) halo_issue(hB, 1);
     b_load(bfA, 0, 0);
-    halo_commit();
+    halo_commit(hA);
     __syncthreads();
     int cg = 0, tap = 0;                                           // the (chunk, tap) step being computed
     int cgn = 0, tapn = 0;                                         // ... and the one whose weights are being fetched
     auto one_step = [&](const BFrag& use, BFrag& fill) {
-        if (tap == 0 && cg + 1 < nch) halo_issue(cg + 1);          // in flight during all taps of this chunk
+        if (tap == 0) {                                            // in flight during all taps of this chunk (and the next)
+            if constexpr (PD2) {
+                // chunk c lives in set c & 1; chunk cg's set has just been committed, so it takes chunk cg + 2
+                if (cg + 2 < nch) { if (cg & 1) halo_issue(hB, cg + 2); else halo_issue(hA, cg + 2); }
+            } else {
+                if (cg + 1 < nch) halo_issue(hA, cg + 1);
+            }
+        }
         if (++tapn == taps_of(cgn)) { tapn = 0; ++cgn; }
         if (cgn < nch) b_load(fill, cgn, tapn);
         compute(cg, tap, use);
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
             tap = 0;
             if (++cg < nch) {
                 __syncthreads();                                   // every wave is done with the old halo
-                halo_commit();
+                if (PD2 && (cg & 1)) halo_commit(hB); else halo_commit(hA);
                 __syncthreads();
             }
         }

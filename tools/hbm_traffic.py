@@ -7,7 +7,11 @@ roofline.traffic.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out/f --output-format csv -- python bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out/w --output-format csv -- python bench.py ...
-    python tools/hbm_traffic.py out/f out/w
+    python tools/hbm_traffic.py out/f out/w [key]
+
+`key` names the leg the passes were taken on (default "f16x3_256"; e.g. "bf16_256", "bf16_512"): the result is stored
+under that key of profiles/hbm_traffic_latest.json (the key-less top level keeps mirroring the f16x3_256 leg for older
+readers).
 """
 import collections
 import csv
@@ -54,9 +58,21 @@ def main():
            "collected": datetime.date.today().isoformat() + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of "
                         "bench.py --precision f16x3 (serialised branches)",
            "source": [fd, wd]}
+    key = sys.argv[3] if len(sys.argv) > 3 else "f16x3_256"
+    out["leg"] = key
+    out["collected"] = out["collected"].replace("--precision f16x3", "on the leg '%s'" % key)
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(repo, "profiles", "hbm_traffic_latest.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    path = os.path.join(repo, "profiles", "hbm_traffic_latest.json")
+    try:
+        allk = json.load(open(path))
+    except (OSError, ValueError):
+        allk = {}
+    legs = allk.get("legs", {})
+    legs[key] = out
+    top = dict(legs.get("f16x3_256", out))
+    top["legs"] = legs
+    with open(path, "w") as f:
+        json.dump(top, f, indent=1)
     print(json.dumps(out))
 
 
