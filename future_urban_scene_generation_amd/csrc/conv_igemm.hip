@@ -370,6 +370,9 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
                 slab += n;
             }
         }
+        // (Round 3 tried 16 x 16 pixel patches for the 32 / 64-column tiles - half the workgroups, twice the work each,
+        // halo 1.27x instead of 1.41x of the patch: every such launch got 13 - 51 % SLOWER (32 -> 32 1x1 at 256 x 256
+        // 130 -> 186 us, 64 -> 32 3x3 311 -> 351 us), conv time of the pass 23.9 -> 24.5 ms.  Dropped.)
         h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
         h.c.MT = (int)x0.n * h.tiles_per_img;
         if (d->tile_list) {

@@ -148,8 +148,39 @@ __device__ __forceinline__ void epi_store(const ConvK& p, const PixOff& po, cons
 // accesses: 4x fewer memory instructions, 256-byte contiguous runs per pixel.
 // `pix(row, po)` maps a row of the wave tile to its destination pixel offsets (false = out of range).
 // second half of the vectorised epilogue: the wave's tile is in `wlds` ([TM*32 rows][TN*32 columns] floats)
+// Residual values of the wave's tile, fetched BEFORE the accumulators take their detour through LDS: the loads
+// (16 bytes per lane and pass, TM * ITER passes) then travel while the tile is written to LDS, the waves meet and the
+// rows are read back, instead of each pass waiting for its own load (the residual add cost a 128 -> 128 3x3 layer at
+// 256 x 256 10 % of its time, tools/layer_variants_exp.py).  After the main loop the operand fragments are dead, so
+// the 64 registers are there.
+template <int TM, int TN> struct ResRegs {
+    static constexpr int Q = TN * 8, R = 64 / Q, ITER = 32 / R;
+    f32x4 v[TM][ITER];
+};
+template <int TM, int TN, typename PixFn>
+__device__ __forceinline__ void res_prefetch(const ConvK& p, int lane, int ncol_base, PixFn pix, ResRegs<TM, TN>& rr) {
+    constexpr int Q = ResRegs<TM, TN>::Q, R = ResRegs<TM, TN>::R, ITER = ResRegs<TM, TN>::ITER;
+    const int c4 = lane % Q;
+    const int n = ncol_base + c4 * 4;
+    const bool nvalid = n < p.Cout;
+    PixOff co;
+    co.d = co.r0 = co.r1 = 0;
+    if (nvalid) chan_offsets(p, n, co);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = i * 32 + it * R + lane / Q;
+            PixOff po;
+            const bool ok = pix(row, po);
+            const float* ptr = (nvalid && ok) ? p.res0 + po.r0 + co.r0 : p.zeros;
+            rr.v[i][it] = *(const f32x4*)ptr;
+        }
+}
+
 template <int TM, int TN, typename PixFn, typename StatFn>
-__device__ __forceinline__ void epilogue_rows(const ConvK& p, float* wlds, int lane, int ncol_base, PixFn pix, StatFn stat_base) {
+__device__ __forceinline__ void epilogue_rows(const ConvK& p, float* wlds, int lane, int ncol_base, PixFn pix, StatFn stat_base,
+                                              const ResRegs<TM, TN>& rr, bool use_rr) {
     constexpr int PITCH = TN * 32;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -183,7 +214,8 @@ __device__ __forceinline__ void epilogue_rows(const ConvK& p, float* wlds, int l
             for (int c = 0; c < 4; ++c) v[c] = act_apply(fmaf(v[c], wsc[c], bs[c]), p.act);
             vals[it] = v;
             if (nvalid && ok) {
-                if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
+                if (use_rr) v += rr.v[i][it];
+                else if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
                 if (p.res1) v += *(const f32x4*)(p.res1 + po.r1 + co.r1);
                 *(f32x4*)(p.dst + po.d + co.d) = v;
             }
@@ -227,14 +259,15 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 wlds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
-    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base);
+    ResRegs<TM, TN> none;
+    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base, none, false);
 }
 
 // the same for accumulators of v_mfma_f32_16x16x32_f16 tiles: acc[row group of 16][column group of 16], C/D map
 // col = lane & 15, row = (lane >> 4) * 4 + reg
 template <int TM, int TN, typename PixFn, typename StatFn>
 __device__ __forceinline__ void epilogue_vec16(const ConvK& p, float* wlds, const f32x4 (&acc)[2 * TM][2 * TN], int lane,
-                                               int ncol_base, PixFn pix, StatFn stat_base) {
+                                               int ncol_base, PixFn pix, StatFn stat_base, const ResRegs<TM, TN>& rr, bool use_rr) {
     constexpr int PITCH = TN * 32;
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i)
@@ -243,7 +276,7 @@ __device__ __forceinline__ void epilogue_vec16(const ConvK& p, float* wlds, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 wlds[(i * 16 + (lane >> 4) * 4 + r) * PITCH + j * 16 + (lane & 15)] = acc[i][j][r];
-    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base);
+    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base, rr, use_rr);
 }
 
 // ---- in-launch split-K combine ---------------------------------------------------------------------------------

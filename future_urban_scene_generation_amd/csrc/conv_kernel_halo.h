@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const ConvK& p = hk.c;
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
+    constexpr int PR = BM / 16;                    // patch rows
     static_assert(BM == 128 && WM * WN == 4, "8x16 pixel patch, 4 waves");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int HP = hk.HH * hk.HW;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     if (hk.tile_list) { b = mt / hk.tile_count; t2 = hk.tile_list[mt - b * hk.tile_count]; }
     else { b = mt / hk.tiles_per_img; t2 = mt - b * hk.tiles_per_img; }
     const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
-    const int oy0 = ty * 8, ox0 = tx * 16;
+    const int oy0 = ty * PR, ox0 = tx * 16;
 
     // ---- halo items of this thread: pixel index inside the source image + validity (same for every chunk)
     int hpix[NI];                                   // iy * W + ix of the (reflected / clamped) source pixel
@@ -174,7 +175,6 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const int nch0 = hk.s2d ? 4 * nchq : p.C0 / CH, nch = nch0 + hk.c1k / CH;
     const int nch32 = (p.C0 + hk.c1k) >> 5;
     const int ntaps = hk.kh * hk.kw;
-    auto taps_of = [&](int cg) { return hk.s2d ? hk.qtaps[cg / nchq] : ntaps; };
 
     if (p.touch_w && gridDim.x <= TOUCH_MAX_WGS) {
         // this wave column's weight slabs: TN * FPT KiB contiguous per (tap, chunk) slab, nslabs slabs wstep apart;
@@ -192,26 +192,24 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     }
 
-    // Staging registers of one chunk's halo.  Narrow tiles (FUSG_HALO_PD2 builds, TM * TN <= 2: the VUnet's 32 / 64-column
-    // layers) keep TWO sets and fetch two chunks ahead: a chunk's nine taps take ~0.8 us on a 32-column tile, less than
-    // one HBM round trip under load, so with one chunk in flight the workgroup waits for memory at every chunk boundary.
+    // Staging registers of one chunk's halo.  (Tried in round 3 and dropped: a second set, fetching two chunks ahead on
+    // the narrow tiles - conv time of the pass 24.5 -> 25.6 ms: those launches are bound by instruction issue, not by
+    // bytes in flight, and the second set only adds instructions.)
+    // (every lambda below is always_inline: left to the inliner, the NI >= 10 instantiations kept the staging lambdas as
+    // real calls and their register sets went to scratch - 336-368 bytes per lane)
     struct HSet { f32x4 r[NI]; f32x4 sc, sh; };
-#ifdef FUSG_HALO_PD2
-    constexpr bool PD2 = TM * TN <= 2;
-#else
-    constexpr bool PD2 = false;
-#endif
-    HSet hA, hB;
-    hA.sc = hB.sc = f32x4{1.f, 1.f, 1.f, 1.f};
-    hA.sh = hB.sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    HSet hA;
+    hA.sc = f32x4{1.f, 1.f, 1.f, 1.f};
+    hA.sh = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto halo_issue = [&](HSet& S, int cg) {
+    // (q, cq) = quadrant and chunk within it of chunk cg in the quadrant form (the callers count them up: no division)
+    auto halo_issue = [&](HSet& S, int cg, int q, int cq) __attribute__((always_inline)) {
         const bool s1 = cg >= nch0;
         const float* base = s1 ? p.src1 : p.src0;
         const int Cs = s1 ? p.Cs1 : p.Cs0;
         int coff = (s1 ? cg - nch0 : cg) * CH + kc * 4;
         long qpix = img_pix0;
-        if (hk.s2d) { const int q = cg / nchq; coff = (cg - q * nchq) * CH + kc * 4; qpix += (q >> 1) * p.W + (q & 1); }
+        if (hk.s2d) { coff = cq * CH + kc * 4; qpix += (q >> 1) * p.W + (q & 1); }
         if (PK == PK_AFFINE) {
             const long o = (long)b * p.pre_bstride + (s1 ? p.C0 : 0) + coff;
             S.sc = *(const f32x4*)(p.pre_scale + o);
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
             S.r[j] = *(const f32x4*)ptr;
         }
     };
-    auto halo_commit = [&](const HSet& S) {
+    auto halo_commit = [&](const HSet& S) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             f32x4 v = S.r[j];
@@ -253,10 +251,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     };
     struct BFrag { h8 f[TN][2][BF ? 1 : 2]; };        // [32-column tile][16-column half][hi, lo] (bf16: one fragment)
     BFrag bfA, bfB;
-    auto b_load = [&](BFrag& F, int cg, int tap) {
-        int ch32 = cg;                                              // 32-channel chunk within its tap's K range
-        if (hk.s2d) { const int q = cg / nchq; tap += hk.qwoff[q]; ch32 = cg - q * nchq; }
-        const _Float16* base = wfr + (long)(tap * nch32 + ch32) * wstep;
+    auto b_load = [&](BFrag& F, const _Float16* base) __attribute__((always_inline)) {            // base: this wave column's part of one (tap, chunk) slab
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -276,10 +271,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     int abase[2 * TM];
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i) abase[i] = (wm * TM * 2 + i) * hk.RP;
-    auto compute = [&](int cg, int tap, const BFrag& F) {
-        int dyp, dxp;                                                  // halo pixel offset of the tap
-        if (hk.s2d) { const int q = cg / nchq; dyp = hk.qtdy[q][tap]; dxp = hk.qtdx[q][tap]; }
-        else { const int ky = tap / hk.kw, kx = tap - ky * hk.kw; dyp = ky * hk.dil; dxp = kx * hk.dil; }
+    auto compute = [&](int dyp, int dxp, const BFrag& F) __attribute__((always_inline)) {          // (dyp, dxp): halo pixel offset of the tap
         const int hx = (lane & 15) + dxp;
         const int toff = dyp * hk.RP + hx * HPITCH + (((lane >> 4) ^ (((hx >> 2) & 1) << 1)) << 3);
         if constexpr (BF) {
@@ -321,31 +313,59 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     };
 
-    // ---- prologue: halo of chunk 0 (and 1) and the first weight fragments
-    halo_issue(hA, 0);
-    if (PD2 && nch > 1) halo_issue(hB, 1);
-    b_load(bfA, 0, 0);
+    // Step bookkeeping without divisions: a step is (chunk, tap); the launch walks chunk-major.  Three cursors - the
+    // step being computed, the step whose weights are being fetched (one ahead) and the chunk whose halo is being
+    // fetched - each counted up with its quadrant / chunk-in-quadrant (quadrant form) or (ky, kx) (dense tap grid).
+    // The weight slab of (tap, chunk) is tap_global * nch32 + chunk32: consecutive taps of a chunk are `tapstride` apart.
+    // (Round 2 derived all of this per step with integer divisions: ~350 mostly scalar instructions per step next to 12
+    // MFMAs on the 32-column tile - PMC: those launches spent 36 % of their wave cycles issuing and 29 % stalled on issue
+    // at an MFMA-pipe busy of 0.22 - 0.30.)
+    const long tapstride = (long)nch32 * wstep;
+    const int s2d = hk.s2d;
+    // computed step
+    int cg = 0, tap = 0, ky = 0, kx = 0, qc = 0, cqc = 0, ntc = s2d ? hk.qtaps[0] : ntaps;
+    // fetched step (weights)
+    int cgn = 0, tapn = 0, qn = 0, cqn = 0, ntn = ntc;
+    const _Float16* wnext = wfr + (long)(s2d ? hk.qwoff[0] : 0) * tapstride;
+    // fetched chunk (halo)
+    int qh = 0, cqh = 0;
+    auto next_halo_chunk = [&]() { if (s2d && ++cqh == nchq) { cqh = 0; ++qh; } };
+
+    // ---- prologue: halo of chunk 0 and the first weight fragments
+    halo_issue(hA, 0, 0, 0);
+    b_load(bfA, wnext);
     halo_commit(hA);
     __syncthreads();
-    int cg = 0, tap = 0;                                           // the (chunk, tap) step being computed
-    int cgn = 0, tapn = 0;                                         // ... and the one whose weights are being fetched
-    auto one_step = [&](const BFrag& use, BFrag& fill) {
-        if (tap == 0) {                                            // in flight during all taps of this chunk (and the next)
-            if constexpr (PD2) {
-                // chunk c lives in set c & 1; chunk cg's set has just been committed, so it takes chunk cg + 2
-                if (cg + 2 < nch) { if (cg & 1) halo_issue(hB, cg + 2); else halo_issue(hA, cg + 2); }
+    auto one_step = [&](const BFrag& use, BFrag& fill) __attribute__((always_inline)) {
+        if (tap == 0 && cg + 1 < nch) {                            // in flight during all taps of this chunk
+            next_halo_chunk();
+            halo_issue(hA, cg + 1, qh, cqh);
+        }
+        // advance the weight cursor to the next step and fetch it
+        wnext += tapstride;
+        if (++tapn == ntn) {
+            tapn = 0;
+            ++cgn;
+            if (s2d) {
+                if (++cqn == nchq) { cqn = 0; ++qn; }
+                ntn = hk.qtaps[qn & 3];
+                wnext = wfr + (long)hk.qwoff[qn & 3] * tapstride + (long)cqn * wstep;
             } else {
-                if (cg + 1 < nch) halo_issue(hA, cg + 1);
+                wnext = wfr + (long)cgn * wstep;
             }
         }
-        if (++tapn == taps_of(cgn)) { tapn = 0; ++cgn; }
-        if (cgn < nch) b_load(fill, cgn, tapn);
-        compute(cg, tap, use);
-        if (++tap == taps_of(cg)) {
-            tap = 0;
+        if (cgn < nch) b_load(fill, wnext);
+        int dyp = ky * hk.dil, dxp = kx * hk.dil;                  // halo pixel offset of the tap
+        if (s2d) { dyp = hk.qtdy[qc & 3][tap]; dxp = hk.qtdx[qc & 3][tap]; }
+        compute(dyp, dxp, use);
+        ++tap;
+        if (++kx == hk.kw) { kx = 0; ++ky; }
+        if (tap == ntc) {
+            tap = 0; ky = 0; kx = 0;
+            if (s2d) { if (++cqc == nchq) { cqc = 0; ++qc; } ntc = hk.qtaps[qc & 3]; }
             if (++cg < nch) {
                 __syncthreads();                                   // every wave is done with the old halo
-                if (PD2 && (cg & 1)) halo_commit(hB); else halo_commit(hA);
+                halo_commit(hA);
                 __syncthreads();
             }
         }
@@ -365,12 +385,15 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         return true;
     };
     auto statfn = [&](int i) -> float* {                       // slot = (patch index, 32-row group of the patch)
-        return p.stats + ((long)b * p.stats_slots + t2 * 4 + ((wm * TM * 32) >> 5) + i) * p.Cout * 2;
+        return p.stats + ((long)b * p.stats_slots + t2 * (BM / 32) + ((wm * TM * 32) >> 5) + i) * p.Cout * 2;
     };
     if (p.vec_epi) {
+        ResRegs<TM, TN> rr;
+        const bool pre = p.res0 != nullptr;
+        if (pre) res_prefetch<TM, TN>(p, lane, nt * BN + wn * TN * 32, pixfn, rr);     // in flight across the barrier and the LDS detour
         __syncthreads();
         float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
-        epilogue_vec16<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn);
+        epilogue_vec16<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn, rr, pre);
         return;
     }
 #pragma unroll
