@@ -331,17 +331,8 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     int qh = 0, cqh = 0;
     auto next_halo_chunk = [&]() { if (s2d && ++cqh == nchq) { cqh = 0; ++qh; } };
 
-    // ---- prologue: halo of chunk 0 and the first weight fragments
-    halo_issue(hA, 0, 0, 0);
-    b_load(bfA, wnext);
-    halo_commit(hA);
-    __syncthreads();
-    auto one_step = [&](const BFrag& use, BFrag& fill) __attribute__((always_inline)) {
-        if (tap == 0 && cg + 1 < nch) {                            // in flight during all taps of this chunk
-            next_halo_chunk();
-            halo_issue(hA, cg + 1, qh, cqh);
-        }
-        // advance the weight cursor to the next step and fetch it
+    // weight cursor -> the next (chunk, tap) step
+    auto advance_w = [&]() __attribute__((always_inline)) {
         wnext += tapstride;
         if (++tapn == ntn) {
             tapn = 0;
@@ -354,6 +345,30 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
                 wnext = wfr + (long)cgn * wstep;
             }
         }
+    };
+
+    // ---- prologue: halo of chunk 0 and the first weight fragments
+    // (Tried in round 3 and left off: weights TWO steps ahead through a ring of three fragment sets for the short steps -
+    // bf16 mode, 16 MFMAs = 256 cycles per step, and the narrow split-fp16 tiles, 12 - 24 MFMAs.  Their waves spend 52 % /
+    // 35 - 38 % of their cycles in s_waitcnt (profiles/r03_stalls_bf16_halo_256.txt, r03_pmc_narrow_layers.txt), yet the
+    // longer lead made both slower: bf16 leg conv 18.15 -> 18.6 ms, f16x3 leg 24.6 -> 25.2 ms.  FUSG_HALO_RING3 builds it.)
+#ifdef FUSG_HALO_RING3
+    constexpr bool RING3 = BF || TM * TN <= 2;
+#else
+    constexpr bool RING3 = false;
+#endif
+    BFrag bfC;
+    halo_issue(hA, 0, 0, 0);
+    b_load(bfA, wnext);
+    if constexpr (RING3) { advance_w(); if (cgn < nch) b_load(bfB, wnext); }
+    halo_commit(hA);
+    __syncthreads();
+    auto one_step = [&](const BFrag& use, BFrag& fill) __attribute__((always_inline)) {
+        if (tap == 0 && cg + 1 < nch) {                            // in flight during all taps of this chunk
+            next_halo_chunk();
+            halo_issue(hA, cg + 1, qh, cqh);
+        }
+        advance_w();                                               // the step fetched now: one (bf16: two) ahead
         if (cgn < nch) b_load(fill, wnext);
         int dyp = ky * hk.dil, dxp = kx * hk.dil;                  // halo pixel offset of the tap
         if (s2d) { dyp = hk.qtdy[qc & 3][tap]; dxp = hk.qtdx[qc & 3][tap]; }
@@ -370,11 +385,22 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
             }
         }
     };
-    for (;;) {
-        one_step(bfA, bfB);
-        if (cg >= nch) break;
-        one_step(bfB, bfA);
-        if (cg >= nch) break;
+    if constexpr (RING3) {
+        for (;;) {
+            one_step(bfA, bfC);
+            if (cg >= nch) break;
+            one_step(bfB, bfA);
+            if (cg >= nch) break;
+            one_step(bfC, bfB);
+            if (cg >= nch) break;
+        }
+    } else {
+        for (;;) {
+            one_step(bfA, bfB);
+            if (cg >= nch) break;
+            one_step(bfB, bfA);
+            if (cg >= nch) break;
+        }
     }
 
     if constexpr (!BF) report_range(p, amax);

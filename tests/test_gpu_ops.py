@@ -404,6 +404,29 @@ def test_rowsplit_head(cout, act, fn):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("cin,cout,pre", [(6, 128, L.PRE_ELU), (3, 32, L.PRE_ELU), (8, 64, L.PRE_NONE), (5, 12, L.PRE_RELU)])
+def test_pointwise_from_few_channels(cin, cout, pre, precision):
+    """1x1 from <= 8 channels (the VUnet's NiN stems) runs on the streaming fp32-FMA kernel under the split-fp16
+    precision: same bits as the exact-fp32 MFMA kernel (an fmaf chain in channel order), residual and activation fused."""
+    x = _rand(2, cin, 24, 40, seed=71)
+    w = _rand(cout, cin, 1, 1, seed=72, scale=0.4)
+    b = _rand(cout, seed=73)
+    res = _rand(2, cout, 24, 40, seed=74)
+    plan = pack.pack_conv(w, b)
+    xin = _nhwc(x)
+    rin = _nhwc(res)
+    got = ops.conv(plan, xin, pre_op=pre, res0=rin, act=L.ACT_TANH, precision="f16x3")
+    fam = ops.last_conv_kernel()
+    want32 = ops.conv(plan, xin, pre_op=pre, res0=rin, act=L.ACT_TANH, precision="f32")
+    xp = {L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre]
+    ref = torch.tanh(F.conv2d(xp, w, b)) + res
+    _close(got, ref)
+    if cout % 4 == 0:
+        assert fam == 7, fam
+        assert torch.equal(got, want32)
+    assert not ops.range_exceeded(dev())
+
+
 # ---- split-fp16 contraction: accuracy over operand scale, and the range guard -----------------------------------
 SWEEP_LAYERS = [   # name, cin, cout, k, pad, H, W, pre-op, expected kernel family (fusg_last_conv_kernel)
     ("halo_k2304", 256, 64, 3, 1, 16, 16, L.PRE_NONE, 2),

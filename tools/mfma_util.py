@@ -27,8 +27,8 @@ def main():
             fam = family(r["Kernel_Name"])
             tot[fam][r["Counter_Name"]] += float(r["Counter_Value"])
             nd[fam].add(r["Dispatch_Id"])
-    print("MFMA pipe utilisation of the crop pass from PMC counters (MI355X, cfg 1, f16x3, branches serialised)")
-    print(f"{'kernel family':28s} {'dispatches':>10s} {'CU-busy cycles':>16s} {'MFMA pipe busy':>15s} {'MFMA MOPS F16':>15s}")
+    print("MFMA pipe utilisation of the crop pass from PMC counters (MI355X, branches serialised; leg = the bench.py command of the pass)")
+    print(f"{'kernel family':28s} {'dispatches':>10s} {'CU-busy cycles':>16s} {'MFMA pipe busy':>15s} {'MFMA MOPS F16+BF16':>18s}")
     conv_busy = conv_cu = 0.0
     rows = []
     for fam, c in tot.items():
@@ -36,7 +36,8 @@ def main():
         if (fam.startswith("conv_") or fam == "hg_bneck_h3") and fam != "conv_splitk_reduce":
             conv_busy += busy
             conv_cu += cu
-        rows.append((cu, fam, len(nd[fam]), busy / (4 * cu) if cu else 0.0, c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)))
+        rows.append((cu, fam, len(nd[fam]), busy / (4 * cu) if cu else 0.0,
+                     c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)))
     print(f"{'all conv kernels':28s} {'':>10s} {conv_cu:16.4g} {conv_busy / (4 * conv_cu) if conv_cu else 0:15.3f}")
     for cu, fam, n, util, mops in sorted(rows, reverse=True)[:14]:
         print(f"{fam:28s} {n:10d} {cu:16.4g} {util:15.3f} {mops:15.4g}")
