@@ -37,7 +37,8 @@ const EnvSwitches& env_switches() {
         EnvSwitches s;
         s.no_vec_epi = getenv("FUSG_NO_VEC_EPI") != nullptr;
         s.no_halo = getenv("FUSG_NO_HALO") != nullptr;
-        s.no_touch = getenv("FUSG_NO_TOUCH") != nullptr;          // no L2 warm-up of the weights (conv_kernel.h, l2_touch)
+        s.no_touch = getenv("FUSG_NO_TOUCH") != nullptr;
+        s.no_pointwise = getenv("FUSG_NO_POINTWISE") != nullptr;  // 1x1 from <= 8 channels on the tap-unit MFMA kernel again          // no L2 warm-up of the weights (conv_kernel.h, l2_touch)
         s.halo_minwg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
         s.halo_bn = getenv("FUSG_HALO_BN") ? atoi(getenv("FUSG_HALO_BN")) : 0;
         return s;

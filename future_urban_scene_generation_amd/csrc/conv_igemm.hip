@@ -52,59 +52,73 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK p, int nph
 
 // Pointwise convolution from at most 8 input channels (the VUnet's NiN stems, 6 -> 128 and 3 -> 32 at full resolution):
 // such a layer is a stream of output stores (1.07 GB for 6 -> 128 at B = 32) with 3 - 8 multiply-adds per output
-// element - nothing for the matrix cores.  One thread per (pixel, 4 output channels): the pixel's channels in two 16-byte
-// loads, the pre-op, an fp32 fmaf chain in channel order per output channel (bit for bit what the exact-fp32 MFMA
-// kernel computes: no fp16 split, no range status to raise), bias / activation / residuals, one 16-byte store.
-// Weights ([cout][<= 8] fp32 from the packed panel) and bias sit in LDS.
+// element - nothing for the matrix cores.  A workgroup takes PW_ITEMS * 256 / n4 consecutive pixels (n4 = cout_pad / 4):
+//   1. its pixels' input channels are loaded ONCE (one 16-byte load per thread), pre-processed (ELU / ReLU) and parked in
+//      LDS - with one thread per (pixel, 4 output channels) every thread of a pixel would otherwise redo the 8 ELUs;
+//   2. a thread's 4 output columns are the same for all of its items (256 % n4 == 0): their 8 weight vectors and the bias
+//      are read once into registers;
+//   3. per item: the pixel's 8 values from LDS (two broadcast reads), an fp32 fmaf chain per output channel in the exact-
+//      fp32 MFMA kernel's k order (bit for bit what that kernel computes: no fp16 split, no range status to raise), bias /
+//      activation / residuals, ONE fully coalesced 16-byte store per lane.
+// (Measured on the way: 4 columns per thread with per-thread ELUs and 64-bit index divisions 0.47 ms for 6 -> 128 at B = 32,
+// 16 columns per thread - four 16-byte stores 64 bytes apart between lanes - 0.62 ms; the tap-unit MFMA kernel 0.31 ms.)
+constexpr int PW_ITEMS = 16;
 __global__ __launch_bounds__(256) void conv_pointwise_small(const ConvK p, int npix) {
     extern __shared__ __attribute__((aligned(16))) float smem_pw[];
-    float* wl = smem_pw;                               // [Cout_pad][8]
-    for (int i = threadIdx.x; i < p.Cout_pad * 8; i += 256) {
-        const int n = i >> 3, c = i & 7;
+    const int n4 = p.Cout_pad >> 2;                    // threads per pixel; divides 256 (host-checked)
+    const int ppb = PW_ITEMS * 256 / n4;               // pixels per workgroup
+    float* wl = smem_pw;                               // [8 channels][Cout_pad]
+    float* xs = smem_pw + p.Cout_pad * 8;              // [ppb][8]: pre-processed inputs
+    const int t = threadIdx.x;
+    for (int i = t; i < p.Cout_pad * 8; i += 256) {
+        const int c = i / p.Cout_pad, n = i - c * p.Cout_pad;
         wl[i] = c < p.C0 ? p.wpack[(long)n * p.K_pad + c] : 0.f;
     }
-    __syncthreads();
-    const int n4 = p.Cout_pad >> 2;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)npix * n4) return;
-    const int c4 = (int)(idx % n4);
-    const int m = (int)(idx / n4);
-    const int n = c4 * 4;
-    if (n >= p.Cout) return;
     const int hw = p.Ho * p.Wo;
-    const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    const float* xp = p.src0 + ((long)(b * p.H + oy) * p.W + ox) * p.Cs0;
-    float x[8];
-    const f32x4 x0 = *(const f32x4*)xp;
-    x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3];
-    if (p.C0 > 4) { const f32x4 x1 = *(const f32x4*)(xp + 4); x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3]; }
-    else { x[4] = x[5] = x[6] = x[7] = 0.f; }
+    const int pix0 = blockIdx.x * ppb;
+    const int halves = p.C0 > 4 ? 2 : 1;               // 16-byte pieces per pixel
+    for (int i = t; i < ppb * 2; i += 256) {
+        const int pl = i >> 1, hf = i & 1, m = pix0 + pl;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < npix && hf < halves) {
+            const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            v = *(const f32x4*)(p.src0 + ((long)(b * p.H + oy) * p.W + ox) * p.Cs0 + hf * 4);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float v = x[c];
-        if (p.pre_op == FUSG_PRE_ELU) v = elu1(v);
-        else if (p.pre_op == FUSG_PRE_RELU) v = fmaxf(v, 0.f);
-        x[c] = v;
+            for (int c = 0; c < 4; ++c) {
+                if (p.pre_op == FUSG_PRE_ELU) v[c] = elu1(v[c]);
+                else if (p.pre_op == FUSG_PRE_RELU) v[c] = fmaxf(v[c], 0.f);
+            }
+        }
+        *(f32x4*)(xs + pl * 8 + hf * 4) = v;
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int c4 = t % n4, n = c4 * 4, pl0 = t / n4, ppi = 256 / n4;     // this thread's columns; pixels advance by ppi per item
+    if (n >= p.Cout) return;
+    f32x4 w[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 w0 = *(const f32x4*)(wl + (n + j) * 8), w1 = *(const f32x4*)(wl + (n + j) * 8 + 4);
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a = fmaf(x[c], w0[c], a);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a = fmaf(x[4 + c], w1[c], a);     // (channels past C0 multiply zero weights)
-        acc[j] = a;
-    }
+    for (int c = 0; c < 8; ++c) w[c] = *(const f32x4*)(wl + c * p.Cout_pad + n);
     const f32x4 bias = *(const f32x4*)(p.bias + n);
-    const long Y = (long)oy * p.osy + p.ooy[0], X = (long)ox * p.osx + p.oox[0];
-    f32x4 v;
+#pragma unroll 4
+    for (int it = 0; it < PW_ITEMS; ++it) {
+        const int pl = it * ppi + pl0, m = pix0 + pl;
+        if (m >= npix) return;
+        const f32x4 xa = *(const f32x4*)(xs + pl * 8), xb = *(const f32x4*)(xs + pl * 8 + 4);
+        // k order 0, 4, 1, 5, 2, 6, 3, 7: v_mfma_f32_32x32x2_f32 takes k = e from lane half 0 and k = 4 + e from half 1 in the
+        // exact-fp32 kernel; channels past C0 meet zero weights
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = act_apply(fmaf(acc[j], 1.f, bias[j]), p.act);
-    if (p.res0) v += *(const f32x4*)(p.res0 + b * p.r0n + Y * p.r0h + X * p.r0w + n);
-    if (p.res1) v += *(const f32x4*)(p.res1 + b * p.r1n + Y * p.r1h + X * p.r1w + n);
-    *(f32x4*)(p.dst + b * p.dsn + Y * p.dsh + X * p.dsw + p.dst_c_off + n) = v;
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(xb[e], w[4 + e][j], fmaf(xa[e], w[e][j], acc[j]));
+        const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const long Y = (long)oy * p.osy + p.ooy[0], X = (long)ox * p.osx + p.oox[0];
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(fmaf(acc[j], 1.f, bias[j]), p.act);
+        if (p.res0) v += *(const f32x4*)(p.res0 + b * p.r0n + Y * p.r0h + X * p.r0w + n);
+        if (p.res1) v += *(const f32x4*)(p.res1 + b * p.r1n + Y * p.r1h + X * p.r1w + n);
+        *(f32x4*)(p.dst + b * p.dsn + Y * p.dsh + X * p.dsw + p.dst_c_off + n) = v;
+    }
 }
 
 struct TileCfg { int bm, bn; };
@@ -340,10 +354,10 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     if (d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->upsample == 0 && !has1 &&
         d->c0k >= 4 && d->c0k <= 8 && d->ksplit <= 1 && d->store_mode == FUSG_STORE_NORMAL && k.vec_epi && !d->stats_out &&
         d->cout % 4 == 0 && d->pre_op <= FUSG_PRE_ELU && (d->q_oy | d->q_ox) == 0 && !d->tile_list && d->wpack && d->pad_h == 0 &&
-        d->pad_w == 0 && !env_switches().no_halo) {
-        const long total = Ml * (d->cout_pad >> 2);
-        hipLaunchKernelGGL(conv_pointwise_small, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)d->cout_pad * 8 * sizeof(float), s,
-                           k, (int)Ml);
+        d->pad_w == 0 && 256 % (d->cout_pad >> 2) == 0 && !env_switches().no_halo && !env_switches().no_pointwise) {
+        const int n4 = d->cout_pad >> 2, ppb = PW_ITEMS * 256 / n4;
+        hipLaunchKernelGGL(conv_pointwise_small, dim3((unsigned)((Ml + ppb - 1) / ppb)), dim3(256),
+                           (size_t)(d->cout_pad * 8 + ppb * 8) * sizeof(float), s, k, (int)Ml);
         e = hipGetLastError();
         prof_end(0, s);
         if (e != hipSuccess) { set_error("conv2d pointwise launch: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }

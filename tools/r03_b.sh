@@ -2,7 +2,7 @@
 # GPU box: new frame tests first (fast feedback), then the full suite, the default bench and a per-dispatch kernel trace
 set -e
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/r03b
+out=$R/gpurun_out/r03k
 mkdir -p $out
 cd $R
 timeout -k 10 300 python -m pytest tests/test_gpu_frame.py -x -q > $out/pytest_frame.log 2>&1 || { tail -60 $out/pytest_frame.log; echo FRAME_TESTS_FAILED; }
