@@ -45,7 +45,7 @@ def main():
             qh, qw = kw["q_window"][2], kw["q_window"][3]
         m = b * qh * qw
         fl = plan.flops_per_pixel * m
-        kind = {0: "gen32", 1: "gen16", 2: "halo", 3: "halo-s2", 4: "tapunit"}.get(ops.last_conv_kernel(), "?")
+        kind = {0: "gen32", 1: "gen16", 2: "halo", 3: "halo-s2", 4: "tapunit", 5: "halo-bf16", 6: "bneck", 7: "pointwise"}.get(ops.last_conv_kernel(), "?")
         rows.append((net[0], f"{sum(plan.c_split)}->{plan.cout} k{plan.kh} s{plan.stride} d{plan.dil} up{plan.upsample} ph{plan.nphase} {kind}",
                      f"{h}x{w}", m, plan.k_pad, e0.elapsed_time(e1), fl))
         return out
