@@ -38,6 +38,7 @@ const EnvSwitches& env_switches() {
         s.no_vec_epi = getenv("FUSG_NO_VEC_EPI") != nullptr;
         s.no_halo = getenv("FUSG_NO_HALO") != nullptr;
         s.no_touch = getenv("FUSG_NO_TOUCH") != nullptr;
+        s.no_ksplit = getenv("FUSG_NO_KSPLIT") != nullptr;        // narrow halo tiles with the M split over the waves (rounds 1-2)
         s.no_pointwise = getenv("FUSG_NO_POINTWISE") != nullptr;  // 1x1 from <= 8 channels on the tap-unit MFMA kernel again          // no L2 warm-up of the weights (conv_kernel.h, l2_touch)
         s.halo_minwg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
         s.halo_bn = getenv("FUSG_HALO_BN") ? atoi(getenv("FUSG_HALO_BN")) : 0;

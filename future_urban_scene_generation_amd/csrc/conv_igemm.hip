@@ -470,7 +470,17 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             const bool bf = want_bf16 && d->wfrag_bf16 != nullptr && (((uintptr_t)d->wfrag_bf16) & 15) == 0;
             if (bf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
-            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk, bf) : bn == 64 ? launch_halo_64(h, hgrid, s, pk, bf) : launch_halo_32(h, hgrid, s, pk, bf);
+            // narrow column tiles of k x k layers on SMALL grids: K split over the waves (conv_kernel_halo.h, KS) when every wave
+            // gets a tap.  Measured per dispatch inside the pass (round 3, same card): grids of 256 - 1024 workgroups 2 - 14 %
+            // shorter (their time is one workgroup's latency); grids of 4096 - 16384 workgroups 19 - 42 % LONGER (the four
+            // partial tiles need 64 KiB of LDS: two workgroups per CU instead of three, and those launches move 3 - 4.4 TB/s -
+            // they live on bytes in flight).  Hence the limit.
+            const int ntaps = d->kh * d->kw;
+            const bool ks_ok = !s2d_form && !d->tile_list && !env_switches().no_ksplit && (long)h.c.MT * h.c.NT <= 1024;
+            const bool k4 = ks_ok && bn == 32 && ntaps >= 4, k2 = ks_ok && bn == 64 && ntaps >= 2;
+            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk, bf)
+                          : bn == 64 ? (k2 ? launch_halo_64k(h, hgrid, s, pk, bf) : launch_halo_64(h, hgrid, s, pk, bf))
+                                     : (k4 ? launch_halo_32k(h, hgrid, s, pk, bf) : launch_halo_32(h, hgrid, s, pk, bf));
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
             note_conv_kernel(bf ? FUSG_CONV_HALO_BF16 : (h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO));
             prof_end(0, s);

@@ -89,7 +89,14 @@ constexpr int halo_waves(int tm, int tn) { return tm * tn == 1 ? 4 : (tm * tn ==
 constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
 #endif
 
-template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE>
+// KS > 1 ("K split over the waves", the narrow column tiles of k x k layers): the workgroup's columns are 32 * WN wide and
+// its 4 / WN waves per column each compute ALL 128 pixels of the patch for every KS-th tap of every chunk; the partial
+// tiles meet in LDS at the end (summed in wave order: deterministic).  Why: with the M split (round 1-2: 32 pixels x 32
+// columns per wave) a (chunk, tap) step is 12 MFMAs = 192 cycles - less than the L2 round trip of the next step's weight
+// fragments, and ~60 bookkeeping instructions per step - so those launches ran at an MFMA-pipe busy of 0.22-0.30
+// (profiles/r03_pmc_narrow_layers.txt); here a step is 48 MFMAs like on the 128-column tile, every wave fetches different
+// weight fragments, and the per-step overhead is paid a quarter as often.  It pays on small grids only (conv_igemm.hip).
+template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE, int KS = 1>
 __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
     constexpr bool BF = MODE == 1;
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
@@ -99,7 +106,8 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
     constexpr int PR = BM / 16;                    // patch rows
-    static_assert(BM == 128 && WM * WN == 4, "8x16 pixel patch, 4 waves");
+    static_assert(BM == 128 && WM * WN * KS == 4, "8x16 pixel patch, 4 waves");
+    static_assert(KS == 1 || (WM == 1 && TN == 1 && TM == 4), "K split: every wave owns the whole patch and one 32-column tile");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int HP = hk.HH * hk.HW;
     _Float16* Ah = smem_h;                         // [HH][RP]: rows of HW pixels x HPITCH halves (+ row padding)
@@ -108,7 +116,8 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN);               // K-split index (0 when KS == 1)
+    const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
     const int kc = t & (CPP - 1);
 
     int tile;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         const int nslabs = ntaps * nch32;                         // (quadrant form: the quadrants' taps add up to kh * kw)
         void* dummy = (char*)smem_h + hk.touch_off;
         const _Float16* wcol = hk.wfrag + (long)(nt * (BN / 32) + wn * TN) * FPT * 64 * 8;
-        for (int L0 = wm * 64; L0 < nslabs * LPS; L0 += WM * 64) {
+        for (int L0 = (wave / WN) * 64; L0 < nslabs * LPS; L0 += WM * KS * 64) {     // the WM * KS waves of a column share the work
             const int L = L0 + lane;
             if (L < nslabs * LPS) {
                 const int sl = L / LPS, q = L - sl * LPS;
@@ -347,6 +356,35 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     };
 
+    if constexpr (KS > 1) {
+        // ---- K split over the waves: this wave's steps are the taps wk, wk + KS, ... of every chunk (dense tap grid only)
+        auto wptr = [&](int cgx, int tapx) __attribute__((always_inline)) { return wfr + (long)tapx * tapstride + (long)cgx * wstep; };
+        halo_issue(hA, 0, 0, 0);
+        if (wk < ntaps) b_load(bfA, wptr(0, wk));
+        halo_commit(hA);
+        __syncthreads();
+        bool odd = false;
+        for (int cgx = 0; cgx < nch; ++cgx) {
+            if (cgx + 1 < nch) halo_issue(hA, cgx + 1, 0, 0);         // in flight during this chunk's taps
+            int kyx = 0, kxx = wk;
+            while (kxx >= hk.kw) { kxx -= hk.kw; ++kyx; }
+            for (int tapx = wk; tapx < ntaps; tapx += KS) {
+                int ntap = tapx + KS, ncg = cgx;                       // this wave's next step: its weights are fetched now
+                if (ntap >= ntaps) { ntap = wk; ++ncg; }
+                const _Float16* wn_ptr = wptr(ncg, ntap);
+                if (!odd) { if (ncg < nch) b_load(bfB, wn_ptr); compute(kyx * hk.dil, kxx * hk.dil, bfA); }
+                else { if (ncg < nch) b_load(bfA, wn_ptr); compute(kyx * hk.dil, kxx * hk.dil, bfB); }
+                odd = !odd;
+                kxx += KS;
+                while (kxx >= hk.kw) { kxx -= hk.kw; ++kyx; }
+            }
+            if (cgx + 1 < nch) {
+                __syncthreads();                                       // every wave is done with the old halo
+                halo_commit(hA);
+                __syncthreads();
+            }
+        }
+    } else {
     // ---- prologue: halo of chunk 0 and the first weight fragments
     // (Tried in round 3 and left off: weights TWO steps ahead through a ring of three fragment sets for the short steps -
     // bf16 mode, 16 MFMAs = 256 cycles per step, and the narrow split-fp16 tiles, 12 - 24 MFMAs.  Their waves spend 52 % /
@@ -403,7 +441,57 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         }
     }
 
+    }
+
     if constexpr (!BF) report_range(p, amax);
+    if constexpr (KS > 1) {
+        // ---- K split: partial tiles -> LDS ([wave][128 rows][32 columns] fp32, over the halo images), summed in wave order by
+        // the wave that finishes those rows: wave (wk, wn) takes rows 128 / KS * wk ... of column tile wn
+        constexpr int RW = 128 / KS, TME = RW / 32;
+        __syncthreads();                                               // every wave is done with the halo images
+        float* slabs = (float*)smem_h;
+        float* mine = slabs + wave * (128 * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(i * 16 + (lane >> 4) * 4 + r) * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
+        __syncthreads();
+        const int rows0 = RW * wk;
+        float* dstw = slabs + wn * (128 * 32) + rows0 * 32;           // column wn's slab of K-split 0: the sum lands here
+        for (int e = lane; e < RW * 8; e += 64) {                      // RW rows x 8 float4
+            f32x4 sum = *(const f32x4*)(dstw + e * 4);
+#pragma unroll
+            for (int k2 = 1; k2 < KS; ++k2) sum += *(const f32x4*)(slabs + (k2 * WN + wn) * (128 * 32) + rows0 * 32 + e * 4);
+            *(f32x4*)(dstw + e * 4) = sum;
+        }
+        auto pixk = [&](int row, PixOff& po) {
+            const int rr = rows0 + row;
+            pix_offsets_yx(p, b, oy0 + (rr >> 4), ox0 + (rr & 15), po);
+            return true;
+        };
+        auto statk = [&](int i) -> float* {
+            return p.stats + ((long)b * p.stats_slots + t2 * 4 + (rows0 >> 5) + i) * p.Cout * 2;
+        };
+        if (p.vec_epi) {
+            ResRegs<TME, 1> none;
+            epilogue_rows<TME, 1>(p, dstw, lane, nt * BN + wn * 32, pixk, statk, none, false);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = lane; e < RW * 32; e += 64) {                 // scalar path: one (row, column) per lane and pass
+                const int row = e >> 5, n = nt * BN + wn * 32 + (e & 31);
+                if (n >= p.Cout) continue;
+                PixOff po, co;
+                pixk(row, po);
+                chan_offsets(p, n, co);
+                epi_store(p, po, co, p.bias[n], p.wscale ? p.wscale[n] : 1.f, dstw[e]);
+            }
+        }
+        return;
+    }
     // ---------------------------------------------------------------- epilogue
     auto pixfn = [&](int row, PixOff& po) {
         const int rr = wm * TM * 32 + row;
@@ -447,20 +535,20 @@ inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_
 // a thread stages at most 10 16-byte items of a 32-channel chunk: halos of up to 320 pixels
 inline bool halo_fits(int HH, int HW) { return HH * HW * 8 <= 2560 && halo_lds_bytes(HH, HW) <= 96 * 1024; }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int KS = 1>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf16) {
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
-    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
+    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour (K split: the four partial tiles)
     const int touch_off = (int)lds;
     lds += TOUCH_LDS_BYTES;
     const int ni = (HP * 8 + 255) / 256;
     if (!halo_fits(k.HH, k.HW)) return hipErrorInvalidValue;
     const void* fn = nullptr;
 #define FUSG_PICK_NI(PKV, MD)                                                                     \
-    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, MD>;                      \
-    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, MD>;                 \
-    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, MD>;
+    if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, MD, KS>;                  \
+    else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, MD, KS>;             \
+    else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, MD, KS>;
     if (bf16) {
         if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 1) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 1) } else { FUSG_PICK_NI(PK_AFFINE, 1) }
     } else {
@@ -478,5 +566,7 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
 hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int, bool);
 hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int, bool);
 hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int, bool);
+hipError_t launch_halo_32k(const HaloK&, dim3, hipStream_t, int, bool);     // K split over the four waves
+hipError_t launch_halo_64k(const HaloK&, dim3, hipStream_t, int, bool);     // K split over two waves per 32-column tile
 
 }  // namespace fusg
