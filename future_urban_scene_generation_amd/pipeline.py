@@ -386,8 +386,7 @@ class VehiclePipeline:
             img_bbox = fo.crop_resize(frame, geom_box, (R, R), 0)                              # :58-60
             hg_x = fo.crop_resize(frame, geom_box, (R, R), 1, fo.IMAGENET_MEAN, fo.IMAGENET_STD)   # :61-65
             central = fo.central_crop(img_bbox)                                                # vehicle_utils.py:49-52
-            jobs = [pu.warp_jobs(scene["src_kp"][v], scene["dst_kp"][v], scene["src_vis"][v], scene["dst_vis"][v])
-                    for v in range(V)]
+            jobs = pu.warp_jobs_frame(scene["src_kp"], scene["dst_kp"], scene["src_vis"], scene["dst_vis"])
             warped = pu.warp_planes_batch(scene["src_planes"], jobs)                           # :171-175
             _, geom = fo.mask_bbox_geom(scene["masks"])
             icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], central, geom, R, R)     # :179-180

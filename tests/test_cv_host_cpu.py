@@ -102,3 +102,31 @@ def test_reference_control_flow_of_warp_unwarp():
     assert w2[1].any() and not w2[0].any()                       # symmetry swap alone
     w3, _ = C.warp_unwarp_planes(planes, sq, dst, [1, 1, 0, 0, 0], [0, 0, 1, 1, 1])
     assert not w3.any()                                          # neither symmetric plane visible in dst
+
+
+def test_find_homography_batch_equals_the_scalar_fit():
+    """The vectorised fit used by VehiclePipeline.run_frame (one call for every plane of every vehicle) performs the scalar
+    fit's arithmetic per problem: identical matrices, identical rejections (degenerate and collinear point sets)."""
+    from future_urban_scene_generation_amd.warp_learn import planes_utils as pu
+    g = np.random.default_rng(0)
+    pairs = []
+    for k in range(40):
+        n = 4 if k % 2 else 6
+        s = g.uniform(0, 500, (n, 2))
+        Ht = np.eye(3) + g.normal(0, 0.05, (3, 3))
+        Ht[2, :2] *= 1e-3
+        Ht[2, 2] = 1
+        p = np.c_[s, np.ones(n)] @ Ht.T
+        d = p[:, :2] / p[:, 2:3] + g.normal(0, 0.5, (n, 2))
+        pairs.append((np.int32(s), np.int32(d)))
+    pairs.append((np.zeros((4, 2), np.int32), np.int32(g.uniform(0, 9, (4, 2)))))
+    pairs.append((np.int32([[0, 0], [1, 1], [2, 2], [3, 3]]), np.int32([[0, 0], [1, 0], [0, 1], [1, 1]])))
+    pairs.append((np.int32([[0, 0], [5, 0], [5, 5]]), np.int32([[0, 0], [5, 0], [5, 5]])))          # too few points
+    got = pu.find_homography_batch(pairs)
+    assert len(got) == len(pairs)
+    for (s, d), hb in zip(pairs, got):
+        hs = pu.find_homography(s, d)
+        assert (hs is None) == (hb is None)
+        if hs is not None:
+            assert np.array_equal(hs, hb)
+    assert got[-1] is None and got[-2] is None and got[-3] is None
