@@ -537,15 +537,19 @@ def main():
             FV = 8
             scene = synth_frame(FV, (720, 1280), dev, seed=3)
             scene["vehicle_seeds"] = list(range(FV))
-            pipe.run_frame(scene)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                pipe.run_frame(scene)
-            torch.cuda.synchronize()
-            fdt = (time.perf_counter() - t1) / 3
+            fms = {}
+            for mode, rep in (("eager", False), ("replay", True)):
+                pipe.run_frame(scene, replay=rep)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    pipe.run_frame(scene, replay=rep)
+                torch.cuda.synchronize()
+                fms[mode] = (time.perf_counter() - t1) / 5
+            fdt = fms["replay"]
             extra["frame_mode"] = {"vehicles": FV, "frame": "720x1280", "ms_per_frame": round(fdt * 1e3, 3),
-                                   "vehicles_per_s": round(FV / fdt, 2),
+                                   "vehicles_per_s": round(FV / fdt, 2), "ms_per_frame_eager": round(fms["eager"] * 1e3, 3),
+                                   "issue": "networks as one recorded-plan replay (run_frame(replay=True)); eager beside it",
                                    "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
                                                "paste-back of both composited frames; range check per frame (sync)"}
             del scene

@@ -338,7 +338,7 @@ class VehiclePipeline:
         return self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)] + ([("inpaint", inpaint)] if self.inpaint else []))
 
     # ------------------------------------------------------------------------------------------ per-frame chain
-    def run_frame(self, scene: Dict, check: Optional[str] = "sync") -> Dict:
+    def run_frame(self, scene: Dict, check: Optional[str] = "sync", replay: bool = False) -> Dict:
         """One frame's vehicles from detector boxes to the two composited frames, device-resident: the reference's
         per-vehicle order (trajectory_inference.py:55-250, first frame) batched over the V vehicles of the frame:
 
@@ -356,10 +356,14 @@ class VehiclePipeline:
         masks and plane corner points with Open3D (warp_learn/vehicle_utils.py) - is out of scope: those
         are inputs here, and the pose is an output for that renderer.
 
+        replay=True issues the three networks as ONE recorded-plan replay (`CompiledPass`, recorded on the first frame with
+        this many vehicles and kept per vehicle count) instead of ~370 launches from Python: at 8 vehicles per frame the
+        interpreter, not the GPU, bounds the eager form.
+
         Returns 'kp_idx' int32 [V, 12], 'kp_xy' float32 [V, 12, 2], 'pose' = list of (error, rvec [3, 1], tvec [3, 1]),
         'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8]."""
         rng = torch.get_rng_state() if check == "sync" else None
-        out = self._guarded(self._run_frame, (scene,), check, rng)
+        out = self._guarded(self._run_frame, (scene, replay), check, rng)
         # the reference's host epilogue of the pose fit (argmin over the four starts, sign flip): 4 x 7 numbers per vehicle
         from .utils.pnp_utils import select_and_flip
         rv, tv, er = (t.cpu().numpy() for t in out.pop("_pose_raw"))
@@ -367,7 +371,7 @@ class VehiclePipeline:
         return out
 
     @torch.no_grad()
-    def _run_frame(self, scene):
+    def _run_frame(self, scene, replay=False):
         import numpy as np
 
         from . import frame_ops as fo
@@ -379,7 +383,7 @@ class VehiclePipeline:
         H, W, _ = frame.shape
         bboxes = np.asarray(scene["bboxes"]).reshape(-1, 4)
         V, R = bboxes.shape[0], 256
-        self.vunet.set_vehicle_seeds(scene.get("vehicle_seeds"))
+        seeds = scene.get("vehicle_seeds")
         with torch.cuda.device(dev):
             # ---- uint8 glue on the caller's stream
             geom_box = fo.box_geometry((H, W), bboxes, dev)
@@ -391,35 +395,27 @@ class VehiclePipeline:
             _, geom = fo.mask_bbox_geom(scene["masks"])
             icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], central, geom, R, R)     # :179-180
             vu_x, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["src_sketch"], scene["dst_sketch"], geom, R)   # :203-228
+            # ---- the three networks: the crop pass of `run` (three stream branches), eagerly or as one plan replay
+            nets_in = {"hg_x": hg_x, "icn_x": icn_x, "vu_x": vu_x, "vu_y": vu_y}
+            if replay and not self.inpaint and ops.RECORDER is None:
+                cps = self.__dict__.setdefault("_frame_plans", {})
+                key = (V, ops.PRECISION)
+                cp = cps.get(key)
+                if cp is None or [n.generation for n in self._nets] != cp.generations:
+                    cp = cps[key] = CompiledPass(self, nets_in, seeds)
+                out = dict(cp._issue(nets_in, seeds))
+            else:
+                out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
+            # ---- keypoints -> frame pixels -> pose fit; Lab -> BGR; ordered paste of every vehicle into the two frames
             f32 = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2)))).to(dev)   # noqa: E731
-            focals, centers = f32(scene["focals"]), f32(scene["centers"])
             kp3d = torch.from_numpy(np.asarray(scene["kp3d"], np.float32)).to(dev)
-
-            def hg():
-                hm = self.hg(hg_x)["heatmaps"][-1]
-                idx = ops.argmax_hw(hm)                                                        # :75-79
-                kp = fo.keypoints_to_frame(idx, geom_box, tuple(hm.shape[-2:]))                # :95-97
-                rv, tv, er = cpc_fit_device(focals, centers, kp, kp3d)                         # :104-105
-                return {"kp_idx": idx, "kp_xy": kp, "_rv": rv, "_tv": tv, "_er": er}
-
-            def icn():
-                return {"icn_u8": pu.to_image_device(self.icn(icn_x), True)}                   # :182
-
-            def vunet():
-                vu = self.vunet
-                (do, ds), join = self._side("vunet_shape", lambda: vu.forward_dec_up(vu_y))
-                eo, es = vu.forward_enc_up(vu_x)
-                mu_app, _ = vu.forward_enc_down(eo, es)
-                join()
-                xt, _, _ = vu.forward_dec_down(do, ds, mu_app)                                 # :230-233
-                return {"vunet_u8": ops.to_image_u8(xt)}                                       # :234
-
-            out = self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)])
+            out["kp_xy"] = fo.keypoints_to_frame(out["kp_idx"], geom_box, (R // 4, R // 4))   # :95-97 (64 x 64 heat-maps)
+            out["_pose_raw"] = cpc_fit_device(f32(scene["focals"]), f32(scene["centers"]), out["kp_xy"], kp3d)   # :104-105
+            out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
             back = scene.get("background", frame)
             out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"])       # :184-198
             out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"])   # :236-250
             out["geom"] = geom
-            out["_pose_raw"] = (out.pop("_rv"), out.pop("_tv"), out.pop("_er"))
         return out
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,

@@ -127,6 +127,11 @@ def test_run_frame_against_the_oracle_chain():
         a = got[k].cpu().numpy()
         assert np.array_equal(a[~cover], _scene_cpu(sc)["frame"][~cover]), k        # untouched outside every mask
         assert not np.array_equal(a[cover], _scene_cpu(sc)["frame"][cover]), k       # ... and pasted inside
+    # the recorded-plan form of the same frame (networks as one fusg_plan replay): same bits as the eager form
+    rep = pipe.run_frame(sc, replay=True)
+    rep2 = pipe.run_frame(sc, replay=True)
+    for k in ("kp_idx", "kp_xy", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
+        assert torch.equal(rep[k], got[k]) and torch.equal(rep2[k], got[k]), k
     from oracle import pnp as opnp
     for v in range(V):
         e, rv, tv = got["pose"][v]
