@@ -550,12 +550,16 @@ def up2_phases_ok(x: torch.Tensor, precision: Optional[str] = None) -> bool:
 
 
 def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NONE, pre=None, pre_bstride: int = 0,
-             precision: Optional[str] = None) -> torch.Tensor:
+             precision: Optional[str] = None, ring: Optional[dict] = None) -> torch.Tensor:
     """nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 conv.  `exact` = the 25-tap plan with the upsample fused into its
     gather (pack_conv(..., upsample=1)); `phases` = pack_conv_up2_d2s (one launch) or pack_conv_up2_phases (four) of the same filter.  When the shapes qualify,
-    four 3x3 phase launches on the low-res input (9 MACs per output instead of 25) write the interleaved output and
-    the 25-tap form then recomputes the outermost ring of pixels, the only place the two differ
-    (pack.up2_phase_weights)."""
+    four 3x3 phase launches on the low-res input (9 MACs per output instead of 25) write the interleaved output; the
+    outermost ring of pixels, the only place where the phase form and the reflect-padded 25-tap form differ
+    (pack.up2_phase_weights), is then rewritten: by four one-pixel-wide windows of the 25-tap form, or - with `ring`
+    (pack.pack_conv_up2_ring) - by twelve small 3x3 launches whose weights are regrouped for the border (9 MACs there
+    too).  Measured (round 3, same card): the twelve launches, eight of them 32 - 4000 output pixels small, cost as much as the
+    four efficient 25-tap windows (conv 23.2 vs 23.3 - 23.7 ms per step, 1437 vs 1426 crops/s), so the networks do not
+    pass `ring` unless FUSG_UP2_RING9 is set."""
     if phases is None or not up2_phases_ok(x, precision):
         return conv(exact, x, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)
     b, c, h, w = x.shape
@@ -570,6 +574,13 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
         for ph, plan in enumerate(phases):
             conv(plan, x, out=out, out_stride=2, out_off=(ph >> 1, ph & 1), pre_op=pre_op, pre=pre,
                  pre_bstride=pre_bstride, precision=precision, ksplit=1 if halo else 0)
+    if ring is not None:
+        from .pack import up2_ring_launches
+        for ry, rx, win, off in up2_ring_launches(h, w):
+            if win[2] > 0 and win[3] > 0:
+                conv(ring[(ry, rx)], x, out=out, q_window=win, out_stride=2, out_off=off, pre_op=pre_op, pre=pre,
+                     pre_bstride=pre_bstride, precision=precision)
+        return out
     # the outermost ring of output pixels, with the 25-tap form: four one-pixel-wide windows of the full convolution
     for win in ((0, 0, 1, 2 * w), (2 * h - 1, 0, 1, 2 * w), (0, 0, 2 * h, 1), (0, 2 * w - 1, 2 * h, 1)):
         conv(exact, x, out=out, q_window=win, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride, precision=precision)

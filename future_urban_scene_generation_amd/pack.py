@@ -271,6 +271,49 @@ def up2_phase_weights(weight: torch.Tensor) -> List[torch.Tensor]:
     return out
 
 
+# The outermost ring of nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5, also from the low-resolution side.  For an output row y the
+# five taps ky read upsampled rows y - 2 .. y + 2 (reflected at the border), i.e. low-res rows Y - 1, Y, Y + 1 of Y = y >> 1:
+#   "e" (y = 2Y, interior): Y-1, Y-1, Y, Y, Y+1      "o" (y = 2Y + 1, interior): Y-1, Y, Y, Y+1, Y+1        (= UP2_GROUPS)
+#   "f" (y = 0):  u[2], u[1], u[0], u[1], u[2]  = low-res rows 1, 0, 0, 0, 1              -> offsets +1, 0, 0, 0, +1
+#   "l" (y = 2H-1): u[2H-3], u[2H-2], u[2H-1], u[2H-2], u[2H-3] = rows H-2, H-1, H-1, H-1, H-2 -> offsets -1, 0, 0, 0, -1
+# and the same along x: every ring pixel is a 3x3 convolution of the low-res image with regrouped weights (9 MACs instead of
+# the 25 of the exact form the ring was recomputed with in rounds 1-2).
+UP2_ROWMAP = {"e": (0, 0, 1, 1, 2), "o": (0, 1, 1, 2, 2), "f": (2, 1, 1, 1, 2), "l": (0, 1, 1, 1, 0)}
+
+
+def up2_border_weights(weight: torch.Tensor, ry: str, rx: str) -> torch.Tensor:
+    """[cout, cin, 3, 3] weights of the low-res 3x3 convolution that gives the output pixels of row kind `ry` and column
+    kind `rx` (UP2_ROWMAP); sums in fixed (ky, kx ascending) order."""
+    w = weight.detach().to("cpu", torch.float32)
+    assert w.shape[2] == 5 and w.shape[3] == 5, w.shape
+    wp = torch.zeros(w.shape[0], w.shape[1], 3, 3, dtype=torch.float32)
+    for ky in range(5):
+        for kx in range(5):
+            a, b = UP2_ROWMAP[ry][ky], UP2_ROWMAP[rx][kx]
+            wp[:, :, a, b] = wp[:, :, a, b] + w[:, :, ky, kx]
+    return wp
+
+
+def up2_ring_launches(h: int, w: int):
+    """The twelve windows that tile the outermost ring of the 2h x 2w output: (row kind, column kind, low-res window
+    (Y0, X0, nY, nX), output parity (py, px)); output pixel = (2 Y + py, 2 X + px)."""
+    out = []
+    for ry, Y0, py in (("f", 0, 0), ("l", h - 1, 1)):                  # top and bottom row
+        out += [(ry, "e", (Y0, 1, 1, w - 1), (py, 0)), (ry, "o", (Y0, 0, 1, w - 1), (py, 1)),
+                (ry, "f", (Y0, 0, 1, 1), (py, 0)), (ry, "l", (Y0, w - 1, 1, 1), (py, 1))]
+    for rx, X0, px in (("f", 0, 0), ("l", w - 1, 1)):                  # left and right column without the corners
+        out += [("e", rx, (1, X0, h - 1, 1), (0, px)), ("o", rx, (0, X0, h - 1, 1), (1, px))]
+    return out
+
+
+def pack_conv_up2_ring(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> dict:
+    """{(row kind, column kind): ConvPlan} for the twelve kind pairs of up2_ring_launches (edge-replicate padding 1: the
+    offsets a border kind does not use carry zero weights)."""
+    from . import _lib as L
+    kinds = sorted({(ry, rx) for ry, rx, _, _ in up2_ring_launches(4, 4)})
+    return {k: pack_conv(up2_border_weights(weight, *k), bias, stride=1, pad=1, pad_mode=L.PAD_REPLICATE) for k in kinds}
+
+
 def pack_conv_up2_d2s(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> ConvPlan:
     """The four phase convolutions of up2_phase_weights stacked along the output channels - phase 2*py+px in channel
     block [(2*py+px)*cout, +cout) - as ONE 3x3 conv (edge-replicate padding 1) whose DepthToSpace store

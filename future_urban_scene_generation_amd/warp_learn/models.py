@@ -126,7 +126,7 @@ class G_Resnet(FusedNet):
              "down": [self._pack_block(enc[1 + i], device) for i in range(nd)],
              "enc_res": self._pack_res(enc[1 + nd], device),
              "dec_res": self._pack_res(dec[0], device),
-             "up": [], "up_phases": [], "ln": [],
+             "up": [], "up_phases": [], "up_ring": [], "ln": [],
              "head": self._pack_head(dec[1 + 2 * nd], device)}
         for i in range(nd):
             blk = dec[2 + 2 * i]
@@ -137,6 +137,10 @@ class G_Resnet(FusedNet):
             ok = blk.kernel_size == 5 and blk.padding == 2 and blk.stride == 1 and blk.pad_type == "reflect"
             ok = ok and blk.conv.weight.shape[0] % 4 == 0
             P["up_phases"].append(pack.pack_conv_up2_d2s(blk.conv.weight, blk.conv.bias).to(device) if ok else None)
+            # ... and, on request only (FUSG_UP2_RING9: measured no faster than the four 25-tap windows, ops.conv_up2), the
+            # outermost ring of output pixels as twelve border-specific 3x3 launches (pack.pack_conv_up2_ring)
+            P["up_ring"].append({k: v.to(device) for k, v in pack.pack_conv_up2_ring(blk.conv.weight, blk.conv.bias).items()}
+                                if ok and ops._env_set("FUSG_UP2_RING9") else None)
             P["ln"].append((dev_vec(blk.norm.gamma, device), dev_vec(blk.norm.beta, device), blk.norm.eps))
         return P
 
@@ -159,9 +163,9 @@ class G_Resnet(FusedNet):
     def _decode(self, P, y: torch.Tensor) -> torch.Tensor:
         y = self._resblocks(P["dec_res"], y)
         pre_op, pre, bs = L.PRE_NONE, None, 0
-        for p, ph, (gamma, beta, eps) in zip(P["up"], P["up_phases"], P["ln"]):
+        for p, ph, rg, (gamma, beta, eps) in zip(P["up"], P["up_phases"], P["up_ring"], P["ln"]):
             if ph is not None and ops.up2_phases_ok(y):
-                y = ops.conv_up2(p, ph, y, pre_op=pre_op, pre=pre, pre_bstride=bs)
+                y = ops.conv_up2(p, ph, y, pre_op=pre_op, pre=pre, pre_bstride=bs, ring=rg)
                 pre = ops.layernorm_stats(y, gamma, beta, eps)     # the border pass rewrites pixels: no fused statistics
             else:
                 y, pre = ops.conv_ln(p, y, gamma, beta, eps, pre_op=pre_op, pre=pre, pre_bstride=bs)

@@ -255,3 +255,36 @@ def test_c_abi_packer_matches_pack_py(cout, cin, k, c0, stride, pad, dil, ups, c
     if frag is not None:
         assert (1 if plan.s2d_ok() else (2 if plan.tapunit_ok() else 0)) == order
         assert np.array_equal(wfrag, frag.contiguous().view(torch.int16).numpy().astype(np.uint16).reshape(-1))
+
+
+def test_up2_ring_weights_reproduce_the_reflect_padded_5x5_on_the_outermost_ring():
+    """nn.Upsample(2) -> ReflectionPad2d(2) -> 5x5 on the outermost ring of output pixels == twelve low-res 3x3 convolutions
+    with border-regrouped weights (pack.up2_border_weights / up2_ring_launches): the windows tile the ring exactly once and
+    the values agree in float64; the fp32 weights are the float64 regrouping rounded by fixed-order fp32 sums."""
+    import torch.nn.functional as F
+    from future_urban_scene_generation_amd import pack
+    torch.manual_seed(0)
+    B, C, H, W, Co = 2, 3, 5, 6, 4
+    x = torch.randn(B, C, H, W, dtype=torch.float64)
+    w = torch.randn(Co, C, 5, 5, dtype=torch.float64)
+    ref = F.conv2d(F.pad(F.interpolate(x, scale_factor=2, mode="nearest"), (2, 2, 2, 2), mode="reflect"), w)
+    out = torch.zeros_like(ref)
+    cnt = torch.zeros(2 * H, 2 * W)
+    xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
+    for ry, rx, (Y0, X0, nY, nX), (py, px) in pack.up2_ring_launches(H, W):
+        wb = torch.zeros(Co, C, 3, 3, dtype=torch.float64)
+        for ky in range(5):
+            for kx in range(5):
+                wb[:, :, pack.UP2_ROWMAP[ry][ky], pack.UP2_ROWMAP[rx][kx]] += w[:, :, ky, kx]
+        assert torch.allclose(pack.up2_border_weights(w.float(), ry, rx).double(), wb, atol=1e-5)
+        full = F.conv2d(xp, wb)
+        for Y in range(Y0, Y0 + nY):
+            for X in range(X0, X0 + nX):
+                out[:, :, 2 * Y + py, 2 * X + px] = full[:, :, Y, X]
+                cnt[2 * Y + py, 2 * X + px] += 1
+    ring = torch.zeros(2 * H, 2 * W, dtype=torch.bool)
+    ring[0] = ring[-1] = True
+    ring[:, 0] = ring[:, -1] = True
+    assert torch.equal(cnt, ring.float())
+    assert float((out[:, :, ring] - ref[:, :, ring]).abs().max()) < 1e-12
+    assert sorted(pack.pack_conv_up2_ring(w.float(), None)) == sorted({(a, b) for a, b, _, _ in pack.up2_ring_launches(H, W)})
