@@ -457,11 +457,19 @@ def main():
             elif prec == "bf16":
                 kern, peak, note = "fusg::conv_halo_h3<..., bf16> + f16x3 kernels for the rest", PEAK_F16_MFMA_TFLOPS, \
                     ("single-pass bf16 on the halo-kernel layers: 1 matrix FLOP per algorithmic FLOP there (peak = dense bf16 MFMA "
-                     "2500 TFLOP/s); the hourglass and the non-halo layers still cost 3")
+                     "2500 TFLOP/s); the hourglass and the non-halo layers still cost 3.  Counters (profiles/r03_*bf16*): neither "
+                     "pipe bounds this leg - MFMA pipe 0.19 busy on its halo launches, HBM 1.9 TB/s = 0.23 of 8 - its waves wait "
+                     "(52 % of their cycles in s_waitcnt / barriers); 'bound' names only the pipe the FLOPs are priced on")
             else:
                 kern, peak, note = "fusg::conv_halo_h3 + hg_bneck_h3 + conv_tapunit_h3 + conv_igemm_h3 (all instantiations)", round(PEAK_F16_MFMA_TFLOPS / 3, 1), \
                     ("split-fp16: every fp32 FLOP costs 3 fp16 matrix FLOPs (ah*wh + ah*wl + al*wh'); peak = dense "
                      "fp16 MFMA peak 2500 TFLOP/s / 3, so frac is the matrix-pipe utilisation")
+            hbm_extra = {}
+            if prec == "bf16" and traffic:
+                # with fp32 activations the HBM bytes do not shrink with the arithmetic: report the leg against that ceiling too
+                step_bytes = traffic * (conv_launches // max(1, args.steps))
+                hbm_extra = {"hbm_bytes_per_step": round(step_bytes), "hbm_tb_per_s": round(step_bytes / (conv_ms / args.steps * 1e-3) / 1e12, 3),
+                             "hbm_frac_of_8tb": round(step_bytes / (conv_ms / args.steps * 1e-3) / 8e12, 4)}
             roofline = {"bound": "mfma", "kernel": kern,
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4),
@@ -474,6 +482,7 @@ def main():
                         "avg_launch_us": round(conv_ms * 1e3 / max(1, conv_launches), 2),
                         "conv_ms_per_step": round(conv_ms / args.steps, 3),
                         "alg_gflop_per_launch": round(gflop_crop * args.batch * args.steps / max(1, conv_launches), 3)}
+            roofline.update(hbm_extra)
         power = sampler.stop() if sampler else None
         tstat = torch.tensor([dt, -dt, 1.0 if out_of_range else 0.0], dtype=torch.float64, device=coll_dev)
         if world > 1:
