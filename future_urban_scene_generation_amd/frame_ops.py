@@ -24,13 +24,24 @@ def box_geometry(image_hw: Tuple[int, int], bboxes: Sequence[Sequence[int]], dev
     """square_crop_from_bbox geometry rows (x0, y0, x1, y1, pad_x_before, pad_y_before, pad_x_after, pad_y_after) of
     host-known boxes (the detector's), as a device int32 [V, 8]."""
     rows = [_geom_row(*square_crop_geometry(image_hw, bb)) for bb in bboxes]
-    return torch.tensor(rows, dtype=torch.int32, device=device)
+    return ops.h2d(rows, device, torch.int32)
+
+
+def _into(out: Optional[torch.Tensor], b: int, c: int, h: int, w: int, dev) -> torch.Tensor:
+    """`out` (a float32 NHWC-physical [b, c, h, w] buffer of an earlier call, e.g. a recorded pass's input: every real
+    channel of every pixel is rewritten, the channel padding stays zero) or a fresh zeroed one."""
+    if out is None:
+        return ops.nhwc_empty(b, c, h, w, dev, zero=True)
+    assert tuple(out.shape) == (b, c, h, w) and out.dtype == torch.float32 and out.stride(1) == 1 and out.device == dev
+    return out
 
 
 def crop_resize(src: torch.Tensor, geom: torch.Tensor, out_hw: Tuple[int, int], mode: int = 0,
-                mean: Optional[Sequence[float]] = None, std: Optional[Sequence[float]] = None) -> torch.Tensor:
+                mean: Optional[Sequence[float]] = None, std: Optional[Sequence[float]] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """src: CUDA uint8 [H, W, 3] (one image, V windows) or [V, H, W, 3] (one image per window); geom: device int32 [V, 8].
-    mode 0 -> uint8 [V, h, w, 3]; mode 1 -> float32 [V, 3, h, w] NHWC-physical, (v/255 - mean)/std; mode 2 -> v/255*2-1."""
+    mode 0 -> uint8 [V, h, w, 3]; mode 1 -> float32 [V, 3, h, w] NHWC-physical, (v/255 - mean)/std; mode 2 -> v/255*2-1.
+    out (modes 1, 2): write into this buffer instead of a fresh one."""
     ops._require_gpu(src, "image")
     if src.dim() == 3:
         src = src[None]
@@ -43,7 +54,7 @@ def crop_resize(src: torch.Tensor, geom: torch.Tensor, out_hw: Tuple[int, int], 
             out = torch.empty((V, h, w, 3), dtype=torch.uint8, device=dev)
             d = _u8desc(out)
         else:
-            out = ops.nhwc_empty(V, 3, h, w, dev, zero=True)
+            out = _into(out, V, 3, h, w, dev)
             d = ops.desc(out)
         m = (C.c_float * 3)(*(mean if mean is not None else (0, 0, 0)))
         s = (C.c_float * 3)(*(std if std is not None else (1, 1, 1)))
@@ -59,7 +70,7 @@ def central_crop(img_bbox: torch.Tensor) -> torch.Tensor:
     V, h, w, _ = img_bbox.shape
     off = int(w * 0.1)
     row = [w // 2 - off, h // 2 - off, w // 2 + off, h // 2 + off, 0, 0, 0, 0]
-    geom = torch.tensor([row] * V, dtype=torch.int32, device=img_bbox.device)
+    geom = ops.h2d([row] * V, img_bbox.device, torch.int32)
     return crop_resize(img_bbox, geom, (h, w), 0)
 
 
@@ -79,12 +90,14 @@ def mask_bbox_geom(masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def vunet_inputs(frame: torch.Tensor, masks: torch.Tensor, src_sketch: torch.Tensor, dst_sketch: torch.Tensor,
-                 geom: torch.Tensor, res: int = 256) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (x float32 [V, 6, res, res], y_tilde float32 [V, 3, res, res]), NHWC-physical (trajectory_inference.py:203-228)."""
+                 geom: torch.Tensor, res: int = 256, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (x float32 [V, 6, res, res], y_tilde float32 [V, 3, res, res]), NHWC-physical (trajectory_inference.py:203-228);
+    out = (x, y) buffers to write into."""
     V, H, W = masks.shape
     dev = frame.device
-    x = ops.nhwc_empty(V, 6, res, res, dev, zero=True)
-    y = ops.nhwc_empty(V, 3, res, res, dev, zero=True)
+    x = _into(out[0] if out else None, V, 6, res, res, dev)
+    y = _into(out[1] if out else None, V, 3, res, res, dev)
     with torch.cuda.device(dev):
         L.check(L.lib().fusg_vunet_inputs(C.byref(_u8desc(frame.contiguous()[None])), C.byref(ops.desc(masks.contiguous().view(V, 1, H, W))),
                                           C.byref(_u8desc(src_sketch.contiguous())), C.byref(_u8desc(dst_sketch.contiguous())),

@@ -258,6 +258,17 @@ def desc(t: Optional[torch.Tensor]) -> L.Tensor:
     return d
 
 
+def h2d(a, device, dtype=None) -> torch.Tensor:
+    """Small host data (a list, a numpy array, a CPU tensor) to the device WITHOUT synchronising the stream: staged in
+    pinned memory (torch's caching host allocator holds the block until the copy has run) and copied asynchronously.
+    `torch.tensor(..., device=...)` / `.to(device)` from pageable memory wait for everything queued on the stream - one
+    such call per frame is enough to serialise `VehiclePipeline.run_frames`' host against its GPU."""
+    t = a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def nhwc_empty(b: int, c: int, h: int, w: int, device, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
     """Logical [b, c, h, w] view over a fresh NHWC buffer whose channel pitch is c rounded up to 4."""
     cp = (c + 3) // 4 * 4

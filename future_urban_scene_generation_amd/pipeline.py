@@ -370,6 +370,71 @@ class VehiclePipeline:
         out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
         return out
 
+    def run_frames(self, scenes, replay: bool = True):
+        """`run_frame` over a sequence of frames (the reference's outer loop, trajectory_inference.py:283-300), software-
+        pipelined one frame deep: frame i+1's host work (40 homography fits, ~40 launches of glue, the networks' replay)
+        is issued while the GPU still runs frame i, and frame i's results are collected afterwards - its range status
+        and raw pose come back through pinned buffers filled by stream-ordered copies and one event, so reading them
+        waits for frame i only.  A generator: yields one `run_frame`-shaped dict per scene, in order; every tensor in it
+        is the caller's (nothing aliases a later frame's buffers).  A frame whose split-fp16 range status is raised is
+        redone in exact fp32 before it is yielded, with the RNG state it was issued under."""
+        from . import ops
+        pending = None
+        for scene in scenes:
+            ticket = self._issue_frame(scene, replay)
+            if pending is not None:
+                yield self._collect_frame(pending)
+            pending = ticket
+        if pending is not None:
+            yield self._collect_frame(pending)
+
+    def _issue_frame(self, scene, replay):
+        from . import ops
+        guarded = ops.range_guarded()
+        rng = torch.get_rng_state() if (guarded and scene.get("vehicle_seeds") is None) else None
+        word = self.status_word() if guarded else None
+        with torch.cuda.device(self.device):
+            if guarded:
+                with ops.defer_range_check(), ops.status_scope(word):
+                    out = self._run_frame(scene, replay)
+            else:
+                out = self._run_frame(scene, replay)
+            # stream-ordered read-back: the three raw pose arrays and the status word into pinned memory, the word cleared
+            # for the next frame (whose launches queue behind these copies), one event to wait on
+            ring = self.__dict__.setdefault("_frame_pins", [])
+            raw = out.pop("_pose_raw")
+            pins = ring.pop() if ring and all(a.shape == b.shape for a, b in zip(ring[-1][0], raw)) else \
+                ([torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in raw], torch.zeros(1, dtype=torch.int32, pin_memory=True))
+            for h, t in zip(pins[0], raw):
+                h.copy_(t, non_blocking=True)
+            if guarded:
+                pins[1].copy_(word[:1], non_blocking=True)
+                word.zero_()
+            ev = torch.cuda.Event()
+            ev.record()
+        return {"out": out, "pins": pins, "event": ev, "scene": scene, "replay": replay, "rng": rng, "guarded": guarded}
+
+    def _collect_frame(self, t):
+        from . import ops
+        from .utils.pnp_utils import select_and_flip
+        t["event"].synchronize()
+        (rv, tv, er), status = t["pins"]
+        if t["guarded"] and int(status[0]) != 0:                  # rare: this frame again, in exact fp32
+            cur = torch.get_rng_state()
+            if t["rng"] is not None:
+                torch.set_rng_state(t["rng"])
+            with ops.defer_range_check(), ops.precision("f32"):
+                out = self.run_frame(t["scene"], check=None, replay=False)
+            if t["rng"] is not None:
+                torch.set_rng_state(cur)
+            self.__dict__["_frame_pins"].append(t["pins"])
+            return out
+        out = t["out"]
+        rv, tv, er = rv.numpy().copy(), tv.numpy().copy(), er.numpy().copy()
+        self.__dict__["_frame_pins"].append(t["pins"])
+        out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
+        return out
+
     @torch.no_grad()
     def _run_frame(self, scene, replay=False):
         import numpy as np
@@ -385,30 +450,37 @@ class VehiclePipeline:
         V, R = bboxes.shape[0], 256
         seeds = scene.get("vehicle_seeds")
         with torch.cuda.device(dev):
+            replay = replay and not self.inpaint and ops.RECORDER is None
+            cps = self.__dict__.setdefault("_frame_plans", {})
+            cp = cps.get((V, ops.PRECISION)) if replay else None
+            if cp is not None and [n.generation for n in self._nets] != cp.generations:
+                cp = None
+            tgt = cp.inputs if cp is not None else {}            # a recorded pass's inputs are written in place
+            # ---- host: the homography fits of every plane of every vehicle (1.2 ms for 8 vehicles), before any launch
+            jobs = pu.warp_jobs_frame(scene["src_kp"], scene["dst_kp"], scene["src_vis"], scene["dst_vis"])
             # ---- uint8 glue on the caller's stream
             geom_box = fo.box_geometry((H, W), bboxes, dev)
             img_bbox = fo.crop_resize(frame, geom_box, (R, R), 0)                              # :58-60
-            hg_x = fo.crop_resize(frame, geom_box, (R, R), 1, fo.IMAGENET_MEAN, fo.IMAGENET_STD)   # :61-65
+            hg_x = fo.crop_resize(frame, geom_box, (R, R), 1, fo.IMAGENET_MEAN, fo.IMAGENET_STD, out=tgt.get("hg_x"))   # :61-65
             central = fo.central_crop(img_bbox)                                                # vehicle_utils.py:49-52
-            jobs = pu.warp_jobs_frame(scene["src_kp"], scene["dst_kp"], scene["src_vis"], scene["dst_vis"])
             warped = pu.warp_planes_batch(scene["src_planes"], jobs)                           # :171-175
             _, geom = fo.mask_bbox_geom(scene["masks"])
-            icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], central, geom, R, R)     # :179-180
-            vu_x, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["src_sketch"], scene["dst_sketch"], geom, R)   # :203-228
+            icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], central, geom, R, R, out=tgt.get("icn_x"))   # :179-180
+            vu_x, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["src_sketch"], scene["dst_sketch"], geom, R,
+                                         out=(tgt["vu_x"], tgt["vu_y"]) if tgt else None)       # :203-228
             # ---- the three networks: the crop pass of `run` (three stream branches), eagerly or as one plan replay
             nets_in = {"hg_x": hg_x, "icn_x": icn_x, "vu_x": vu_x, "vu_y": vu_y}
-            if replay and not self.inpaint and ops.RECORDER is None:
-                cps = self.__dict__.setdefault("_frame_plans", {})
-                key = (V, ops.PRECISION)
-                cp = cps.get(key)
-                if cp is None or [n.generation for n in self._nets] != cp.generations:
-                    cp = cps[key] = CompiledPass(self, nets_in, seeds)
+            if replay:
+                if cp is None:
+                    cp = cps[(V, ops.PRECISION)] = CompiledPass(self, nets_in, seeds)
                 out = dict(cp._issue(nets_in, seeds))
+                out["vunet_u8"] = out["vunet_u8"].clone()        # the plan's buffers belong to its next replay
+                out["kp_idx"] = out["kp_idx"].clone()
             else:
                 out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
             # ---- keypoints -> frame pixels -> pose fit; Lab -> BGR; ordered paste of every vehicle into the two frames
-            f32 = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2)))).to(dev)   # noqa: E731
-            kp3d = torch.from_numpy(np.asarray(scene["kp3d"], np.float32)).to(dev)
+            f32 = lambda a: ops.h2d(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2))), dev)   # noqa: E731
+            kp3d = ops.h2d(np.asarray(scene["kp3d"], np.float32), dev)
             out["kp_xy"] = fo.keypoints_to_frame(out["kp_idx"], geom_box, (R // 4, R // 4))   # :95-97 (64 x 64 heat-maps)
             out["_pose_raw"] = cpc_fit_device(f32(scene["focals"]), f32(scene["centers"]), out["kp_xy"], kp3d)   # :104-105
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
@@ -459,6 +531,14 @@ class VehiclePipeline:
         return self._branches([("icn", icn), ("vunet", vunet), ("hg", hg)])
 
 
+def _like_layout(t: torch.Tensor) -> torch.Tensor:
+    """A zeroed tensor with exactly `t`'s sizes and strides (an NHWC-physical view keeps its padded channel pitch, so
+    the glue kernels of `run_frame` can write a recorded pass's inputs in place and the stems read them unchanged)."""
+    extent = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride())) if t.numel() else 0
+    base = torch.zeros(extent + 4, dtype=t.dtype, device=t.device)
+    return base.as_strided(t.shape, t.stride())
+
+
 class CompiledPass:
     """A recorded crop pass of a VehiclePipeline (include/fusg.h, fusg_plan): fixed input shapes, persistent input /
     intermediate / output buffers (a private torch memory pool that lives as long as this object), per-pass host data
@@ -478,7 +558,7 @@ class CompiledPass:
             self.pool = torch.cuda.MemPool()
             self.rec = ops.PlanRecorder()
             with torch.cuda.use_mem_pool(self.pool, device=self.device):
-                self.inputs = {k: torch.empty_like(batch[k]).copy_(batch[k]) for k in self.keys}
+                self.inputs = {k: _like_layout(batch[k]).copy_(batch[k]) for k in self.keys}
                 L.check(L.lib().fusg_plan_begin(self.rec.handle), "plan_begin")
                 ops.RECORDER = self.rec
                 try:

@@ -73,8 +73,8 @@ def cpc_fit_device(focals: torch.Tensor, centers: torch.Tensor, points2d: torch.
     b, n = args[0].shape[0], args[0].shape[1]
     assert args[0].shape == (b, n, 3) and args[1].shape == (b, n, 2) and args[2].shape == (b, 2) and args[3].shape == (b, 2)
     with torch.cuda.device(dev):
-        r0 = torch.tensor(START_RVECS, dtype=torch.float32, device=dev)
-        t0 = torch.tensor(START_TVEC, dtype=torch.float32, device=dev)
+        r0 = ops.h2d(START_RVECS, dev, torch.float32)
+        t0 = ops.h2d(START_TVEC, dev, torch.float32)
         rvec = torch.empty((b, 4, 3), dtype=torch.float32, device=dev)
         tvec = torch.empty((b, 4, 3), dtype=torch.float32, device=dev)
         err = torch.empty((b, 4), dtype=torch.float32, device=dev)

@@ -284,7 +284,7 @@ def warp_perspective(src: torch.Tensor, H: Sequence[np.ndarray], dsize: Tuple[in
     (host, double; inverted here in double as OpenCV does) -> [N, dsize[1], dsize[0], 3]."""
     n = src.shape[0]
     minv = np.stack([np.linalg.inv(np.asarray(h, dtype=np.float64)) for h in H]).reshape(n, 9)
-    minv_d = torch.from_numpy(minv).to(src.device)
+    minv_d = ops.h2d(minv, src.device)
     out = torch.empty((n, dsize[1], dsize[0], 3), dtype=torch.uint8, device=src.device)
     with torch.cuda.device(src.device):
         L.check(L.lib().fusg_warp_perspective_u8(C.byref(_u8desc(src)), minv_d.data_ptr(), C.byref(_u8desc(out)),
@@ -362,9 +362,9 @@ def warp_planes_batch(src_planes: torch.Tensor, jobs_per_vehicle) -> torch.Tenso
             dst_idx.append(v * P + j)
             Hs.append(H12)
     if Hs:
-        si = torch.tensor(src_idx, device=flat.device)
+        si = ops.h2d(src_idx, flat.device, torch.int64)
         w1 = warp_perspective(flat[si], Hs, (W, H))
-        warped[torch.tensor(dst_idx, device=flat.device)] = w1
+        warped[ops.h2d(dst_idx, flat.device, torch.int64)] = w1
     return warped.view(V, P, H, W, 3)
 
 
@@ -417,10 +417,14 @@ def icn_inputs_batch(planes: torch.Tensor, sketches: torch.Tensor, centrals: tor
 
 
 def icn_inputs_device(planes: torch.Tensor, sketches: torch.Tensor, centrals: torch.Tensor, geom: torch.Tensor,
-                      icn_w: int = 256, icn_h: int = 256) -> torch.Tensor:
-    """icn_inputs_batch with the crop geometry already on the device (frame_ops.mask_bbox_geom): nothing is read back."""
+                      icn_w: int = 256, icn_h: int = 256, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """icn_inputs_batch with the crop geometry already on the device (frame_ops.mask_bbox_geom): nothing is read back.
+    out: an earlier result's buffer to overwrite (every real channel of every pixel is written)."""
     B, P, H, W, _ = planes.shape
-    out = ops.nhwc_empty(B, 3 * (P + 2), icn_h, icn_w, planes.device, zero=True)
+    if out is None:
+        out = ops.nhwc_empty(B, 3 * (P + 2), icn_h, icn_w, planes.device, zero=True)
+    else:
+        assert tuple(out.shape) == (B, 3 * (P + 2), icn_h, icn_w) and out.dtype == torch.float32 and out.stride(1) == 1
     with torch.cuda.device(planes.device):
         L.check(L.lib().fusg_icn_inputs(C.byref(_u8desc(sketches.contiguous())), C.byref(_u8desc(centrals.contiguous())),
                                         C.byref(_u8desc(planes.reshape(B * P, H, W, 3).contiguous())), geom.data_ptr(),

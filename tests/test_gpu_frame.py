@@ -144,3 +144,70 @@ def test_run_frame_against_the_oracle_chain():
         record("frame_pose_err_rel", rel)
         if rel < 1e-3:                                                            # same minimum reached: same pose
             assert np.abs(opnp.rodrigues(rv) - opnp.rodrigues(orv)).max() < 1e-3 and np.abs(tv - otv).max() < 1e-2 * max(1.0, np.abs(otv).max())
+
+
+@pytest.mark.gpu
+def test_run_frames_pipelined_equals_frame_by_frame():
+    """`run_frames` (frame i+1 issued before frame i is read back; glue written straight into the recorded pass's
+    inputs; pose and range status through pinned buffers) gives, frame for frame, the bits of `run_frame` on the same
+    scene: two different scenes of 3 vehicles and one of 2, interleaved, so that a buffer of an earlier frame reused too
+    early - or pixels of an earlier frame left in a recorded pass's inputs - would show."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    from future_urban_scene_generation_amd import ops
+    ops.set_precision("f16x3")
+    sds = {n: synth_sd(n) for n in ("hg", "icn", "vunet")}
+    pipe = VehiclePipeline(DEV, state_dicts=sds)
+    scenes = []
+    for seed, V in ((11, 3), (12, 3), (13, 2)):
+        sc = synth_frame(V, (360, 640), DEV, seed=seed)
+        sc["vehicle_seeds"] = [seed * 10 + v for v in range(V)]
+        scenes.append(sc)
+    want = [pipe.run_frame(sc) for sc in scenes]                                  # eager, synchronous
+    order = [0, 1, 0, 2, 1, 1, 2]
+    got = list(pipe.run_frames([scenes[i] for i in order]))
+    assert len(got) == len(order)
+    for g, i in zip(got, order):
+        w = want[i]
+        for k in ("kp_idx", "kp_xy", "geom", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
+            assert torch.equal(g[k], w[k]), (i, k)
+        for (e, rv, tv), (we, wrv, wtv) in zip(g["pose"], w["pose"]):
+            assert np.array_equal(np.asarray(e), np.asarray(we), equal_nan=True)
+            assert np.array_equal(rv, wrv, equal_nan=True) and np.array_equal(tv, wtv, equal_nan=True)
+    # the eager (no recorded pass) form of the same pipeline
+    got = list(pipe.run_frames([scenes[2], scenes[0]], replay=False))
+    for g, i in zip(got, (2, 0)):
+        for k in ("kp_idx", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
+            assert torch.equal(g[k], want[i][k]), (i, k)
+
+
+@pytest.mark.gpu
+def test_run_frames_redoes_an_out_of_range_frame_in_fp32():
+    """A frame whose split-fp16 range status is raised comes back recomputed in exact fp32, and its neighbours do not."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    from future_urban_scene_generation_amd import ops
+    ops.set_precision("f16x3")
+    sds = {n: synth_sd(n) for n in ("hg", "icn", "vunet")}
+    pipe = VehiclePipeline(DEV, state_dicts=sds)
+    sc = synth_frame(2, (360, 640), DEV, seed=21)
+    sc["vehicle_seeds"] = [5, 6]
+    with ops.precision("f32"):
+        f32 = pipe.run_frame(sc, check=None)
+    h16 = pipe.run_frame(sc)
+    calls = {"n": 0}
+    orig = pipe._run_frame
+
+    def flagged(scene, replay=False):                                             # raise the status on the 2nd frame only
+        out = orig(scene, replay)
+        calls["n"] += 1
+        if calls["n"] == 2:
+            ops.status_word(DEV)[0] = 1
+        return out
+
+    pipe._run_frame = flagged
+    try:
+        got = list(pipe.run_frames([sc, sc, sc]))
+    finally:
+        pipe._run_frame = orig
+    for k in ("icn_u8", "vunet_u8", "frame_vunet"):
+        assert torch.equal(got[0][k], h16[k]) and torch.equal(got[2][k], h16[k]), k
+        assert torch.equal(got[1][k], f32[k]), k

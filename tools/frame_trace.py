@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""GPU box, analysis tool: N frames through run_frame(replay=True) (one synchronous frame at a time) and through
+run_frames (one frame in flight), wall time per frame; run it under rocprofv3 --kernel-trace --stats to see which
+kernels the per-frame glue spends its GPU time in."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda:0")
+torch.set_grad_enabled(False)
+pipe = VehiclePipeline(dev)
+scenes = []
+for sd in (3, 4):
+    sc = synth_frame(V, (720, 1280), dev, seed=sd)
+    sc["vehicle_seeds"] = list(range(sd * 100, sd * 100 + V))
+    scenes.append(sc)
+for _ in range(3):
+    pipe.run_frame(scenes[0], replay=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(N):
+    pipe.run_frame(scenes[i & 1], replay=True)
+torch.cuda.synchronize()
+print("ms per frame, run_frame(replay=True), one at a time: %.3f" % ((time.perf_counter() - t0) / N * 1e3))
+for _ in pipe.run_frames([scenes[0], scenes[1]]):
+    pass
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+th = 0.0
+for _ in pipe.run_frames([scenes[i & 1] for i in range(N)]):
+    pass
+torch.cuda.synchronize()
+print("ms per frame, run_frames (one frame in flight):        %.3f" % ((time.perf_counter() - t0) / N * 1e3))
+t0 = time.perf_counter()
+for i in range(N):
+    pipe._issue_frame(scenes[i & 1], True)
+th = (time.perf_counter() - t0) / N * 1e3
+torch.cuda.synchronize()
+print("host ms per frame to issue one (no read-back):          %.3f" % th)
