@@ -274,7 +274,10 @@ def nhwc_empty(b: int, c: int, h: int, w: int, device, dtype=torch.float32, zero
     cp = (c + 3) // 4 * 4
     buf = (torch.zeros if zero else torch.empty)((b, h, w, cp), device=device, dtype=dtype)
     t = buf.permute(0, 3, 1, 2)
-    return t if cp == c else t[:, :c]
+    t = t if cp == c else t[:, :c]
+    if zero:
+        t._fusg_zero_pad = True         # this very object: its padding channels hold zeros (see as_nhwc)
+    return t
 
 
 def is_nhwc(t: torch.Tensor) -> bool:
@@ -309,6 +312,10 @@ def as_nhwc(t: torch.Tensor, cpad: int = 4) -> torch.Tensor:
         return t
     b, c, h, w = t.shape
     cp = (c + cpad - 1) // cpad * cpad
+    # a buffer of ours whose pixel pitch already is the layer's and whose padding channels are known to be zero (the
+    # glue kernels' outputs, a recorded pass's inputs): read in place, e.g. the ICN stem on fusg_icn_inputs' 24-pitch rows
+    if getattr(t, "_fusg_zero_pad", False) and is_nhwc(t) and t.stride(3) == cp:
+        return t
     buf = torch.empty((b, h, w, cp), device=t.device, dtype=torch.float32)
     full = buf.permute(0, 3, 1, 2)
     copy4d(t, full, cp)

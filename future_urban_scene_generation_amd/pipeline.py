@@ -536,7 +536,9 @@ def _like_layout(t: torch.Tensor) -> torch.Tensor:
     the glue kernels of `run_frame` can write a recorded pass's inputs in place and the stems read them unchanged)."""
     extent = 1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride())) if t.numel() else 0
     base = torch.zeros(extent + 4, dtype=t.dtype, device=t.device)
-    return base.as_strided(t.shape, t.stride())
+    v = base.as_strided(t.shape, t.stride())
+    v._fusg_zero_pad = True             # only ever written through views of the logical channels (ops.as_nhwc)
+    return v
 
 
 class CompiledPass:

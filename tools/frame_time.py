@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where a run_frame call spends its wall time (GPU box, analysis tool): cProfile of 5 frames of 8 vehicles at 720 x 1280."""
+"""Where the host spends its time issuing one frame (GPU box, analysis tool): cProfile of 10 x VehiclePipeline._issue_frame
+(8 vehicles at 720 x 1280, recorded-pass replay) - what bounds `run_frames` once the GPU side is pipelined."""
 import cProfile
 import os
 import pstats
@@ -16,18 +17,18 @@ torch.set_grad_enabled(False)
 pipe = VehiclePipeline(dev)
 scene = synth_frame(8, (720, 1280), dev, seed=3)
 scene["vehicle_seeds"] = list(range(8))
-for _ in range(2):
-    pipe.run_frame(scene)
+for _ in pipe.run_frames([scene] * 3):
+    pass
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(5):
-    pipe.run_frame(scene)
+for _ in pipe.run_frames([scene] * 10):
+    pass
 torch.cuda.synchronize()
-print("ms per frame", (time.perf_counter() - t0) / 5 * 1e3)
+print("ms per frame (run_frames)", (time.perf_counter() - t0) / 10 * 1e3)
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(5):
-    pipe.run_frame(scene)
-torch.cuda.synchronize()
+for _ in range(10):
+    pipe._issue_frame(scene, True)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
