@@ -544,7 +544,7 @@ def main():
         if args.res == 256:
             from future_urban_scene_generation_amd.pipeline import synth_frame
             FV = 8
-            scene = synth_frame(FV, (720, 1280), dev, seed=3)
+            scene = synth_frame(FV, (720, 1280), dev, seed=3, inpaint=bool(args.inpaint))
             scene["vehicle_seeds"] = list(range(FV))
             fms = {}
             for mode, rep in (("eager", False), ("replay", True)):
@@ -556,7 +556,7 @@ def main():
                 torch.cuda.synchronize()
                 fms[mode] = (time.perf_counter() - t1) / 5
             # a sequence of frames (two scenes alternating), one frame in flight while the next is issued: run_frames
-            scene2 = synth_frame(FV, (720, 1280), dev, seed=4)
+            scene2 = synth_frame(FV, (720, 1280), dev, seed=4, inpaint=bool(args.inpaint))
             scene2["vehicle_seeds"] = list(range(100, 100 + FV))
             for _ in pipe.run_frames([scene, scene2, scene]):
                 pass
@@ -575,7 +575,8 @@ def main():
                                             "before frame i's pose / range status are read back (pinned, one event per frame); "
                                             "run_frame (one synchronous frame at a time) beside it",
                                    "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
-                                               "paste-back of both composited frames; range check per frame"}
+                                               + ("EdgeConnect on every vehicle's box + its resize-back under the pasted crop, " if args.inpaint else "")
+                                               + "paste-back of both composited frames; range check per frame"}
             del scene, scene2
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -105,6 +105,7 @@ _SIGS = {
     "fusg_icn_inputs": (C.c_int, [_TP, _TP, _TP, C.c_void_p, _TP, C.c_void_p]),
     "fusg_lab2bgr_u8": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_paste_back_u8": (C.c_int, [_TP, _TP, C.c_void_p, _TP, C.c_void_p]),
+    "fusg_paste_layers_u8": (C.c_int, [_TP, _TP, C.c_void_p, _TP, C.c_void_p, _TP, C.c_void_p]),
     "fusg_crop_resize_u8": (C.c_int, [_TP, C.c_void_p, _TP, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fusg_vunet_inputs": (C.c_int, [_TP, _TP, _TP, _TP, C.c_void_p, _TP, _TP, C.c_void_p]),
     "fusg_mask_bbox_geom": (C.c_int, [_TP, C.c_void_p, C.c_void_p, C.c_void_p]),

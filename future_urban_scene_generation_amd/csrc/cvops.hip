@@ -288,39 +288,54 @@ __global__ __launch_bounds__(256) void lab2bgr_u8_kernel(U8View src, U8View dst,
 // network image resized back to its crop (cv::resize INTER_LINEAR), with the crop padding removed and placed at
 // crop_xy_min - or 0 where the pixel lies outside that rectangle (the reference pastes from a zero canvas,
 // trajectory_inference.py:190-198); pixels no mask covers keep the frame's value.
-struct PasteIn { U8View net; U8View masks; U8View frame; const int* geom; int V; };   // geom [V][8] as in IcnIn
+// With `rect` (fusg_paste_layers_u8): every vehicle v brings TWO layers, in the reference's order with --inpaint
+// (trajectory_inference.py:133-143 then :184-198, per vehicle, on the running composite): first its inpainted box image
+// resized to the rectangle rgeom[v] = (x0, y0, x1, y1) and written there unmasked, then its masked network image; the
+// last layer covering a pixel wins.
+struct PasteIn { U8View net; U8View masks; U8View frame; const int* geom; int V; U8View rect; const int* rgeom; };   // geom [V][8] as in IcnIn
+
+__device__ __forceinline__ void paste_resized_px(const unsigned char* img, const U8View& nv, int cx, int cy, int cw, int ch, unsigned char* d) {
+    if (cw == nv.w && ch == nv.h) {
+        const unsigned char* s = img + (long)cy * nv.sh + (long)cx * nv.sw;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        return;
+    }
+    int sx, ax0, ax1, sy, ay0, ay1;
+    resize_coef(cx, nv.w, cw, sx, ax0, ax1);
+    resize_coef(cy, nv.h, ch, sy, ay0, ay1);
+    const int sx1 = sx + 1 < nv.w ? sx + 1 : nv.w - 1, sy1 = sy + 1 < nv.h ? sy + 1 : nv.h - 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = img[(long)sy * nv.sh + (long)sx * nv.sw + c] * ax0 + img[(long)sy * nv.sh + (long)sx1 * nv.sw + c] * ax1;
+        const int S1 = img[(long)sy1 * nv.sh + (long)sx * nv.sw + c] * ax0 + img[(long)sy1 * nv.sh + (long)sx1 * nv.sw + c] * ax1;
+        const int o = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        d[c] = (unsigned char)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+}
 __global__ __launch_bounds__(256) void paste_back_kernel(PasteIn a, long total) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int x = (int)(idx % a.frame.w), y = (int)(idx / a.frame.w);
+    unsigned char* d = a.frame.p + (long)y * a.frame.sh + (long)x * a.frame.sw;
     for (int v = a.V - 1; v >= 0; --v) {
-        if (!a.masks.p[(long)v * a.masks.sn + (long)y * a.masks.sh + (long)x * a.masks.sw]) continue;
-        const int* g = a.geom + v * 8;
-        const int cw = g[2] - g[0], ch = g[3] - g[1];
-        // canvas rectangle: starts at crop_xy_min = (x0, y0); holds crop pixels [pad_before, size - pad_after)
-        const int cx = x - g[0] + g[4], cy = y - g[1] + g[5];
-        const int xa = g[6], ya = g[7];
-        unsigned char* d = a.frame.p + (long)y * a.frame.sh + (long)x * a.frame.sw;
-        const bool inside = cx >= g[4] && cy >= g[5] && cx < cw - xa && cy < ch - ya;
-        if (!inside) { d[0] = 0; d[1] = 0; d[2] = 0; return; }
-        const unsigned char* img = a.net.p + (long)v * a.net.sn;
-        if (cw == a.net.w && ch == a.net.h) {
-            const unsigned char* s = img + (long)cy * a.net.sh + (long)cx * a.net.sw;
-            d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        if (a.masks.p[(long)v * a.masks.sn + (long)y * a.masks.sh + (long)x * a.masks.sw]) {
+            const int* g = a.geom + v * 8;
+            const int cw = g[2] - g[0], ch = g[3] - g[1];
+            // canvas rectangle: starts at crop_xy_min = (x0, y0); holds crop pixels [pad_before, size - pad_after)
+            const int cx = x - g[0] + g[4], cy = y - g[1] + g[5];
+            const int xa = g[6], ya = g[7];
+            const bool inside = cx >= g[4] && cy >= g[5] && cx < cw - xa && cy < ch - ya;
+            if (!inside) { d[0] = 0; d[1] = 0; d[2] = 0; return; }
+            paste_resized_px(a.net.p + (long)v * a.net.sn, a.net, cx, cy, cw, ch, d);
             return;
         }
-        int sx, ax0, ax1, sy, ay0, ay1;
-        resize_coef(cx, a.net.w, cw, sx, ax0, ax1);
-        resize_coef(cy, a.net.h, ch, sy, ay0, ay1);
-        const int sx1 = sx + 1 < a.net.w ? sx + 1 : a.net.w - 1, sy1 = sy + 1 < a.net.h ? sy + 1 : a.net.h - 1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int S0 = img[(long)sy * a.net.sh + (long)sx * a.net.sw + c] * ax0 + img[(long)sy * a.net.sh + (long)sx1 * a.net.sw + c] * ax1;
-            const int S1 = img[(long)sy1 * a.net.sh + (long)sx * a.net.sw + c] * ax0 + img[(long)sy1 * a.net.sh + (long)sx1 * a.net.sw + c] * ax1;
-            const int o = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
-            d[c] = (unsigned char)(o < 0 ? 0 : (o > 255 ? 255 : o));
+        if (a.rgeom) {
+            const int* r = a.rgeom + v * 8;
+            if (x >= r[0] && x < r[2] && y >= r[1] && y < r[3]) {
+                paste_resized_px(a.rect.p + (long)v * a.rect.sn, a.rect, x - r[0], y - r[1], r[2] - r[0], r[3] - r[1], d);
+                return;
+            }
         }
-        return;
     }
 }
 
@@ -535,17 +550,28 @@ static int lab2bgr_u8_impl(const fusg_tensor* src, const fusg_tensor* dst, void*
 }
 extern "C" int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream) { return fusg::plan_dispatch(lab2bgr_u8_impl, stream, src, dst); }
 
-static int paste_back_u8_impl(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) {
+static int paste_layers_u8_impl(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* rect,
+                                const int32_t* rect_geom, const fusg_tensor* frame, void* stream) {
     FUSG_CHECK(net && masks && geom && frame && is_u8_hwc(*net, 3) && is_u8_hwc(*frame, 3) && frame->n == 1 && masks->data &&
                masks->dtype == FUSG_U8 && masks->c == 1 && masks->n == net->n && masks->h == frame->h && masks->w == frame->w, "paste_back_u8: shapes");
+    FUSG_CHECK((rect == nullptr) == (rect_geom == nullptr) && (!rect || (is_u8_hwc(*rect, 3) && rect->n == net->n)),
+               "paste_layers_u8: the box images come with their rectangles, one per vehicle");
     PasteIn a;
+    memset(&a, 0, sizeof(a));
     a.net = u8view(*net); a.masks = u8view(*masks); a.frame = u8view(*frame); a.geom = geom; a.V = (int)net->n;
+    if (rect) { a.rect = u8view(*rect); a.rgeom = rect_geom; }
     const long total = frame->h * frame->w;
     hipLaunchKernelGGL(paste_back_kernel, dim3(blocks2d(total)), dim3(256), 0, (hipStream_t)stream, a, total);
     FUSG_LAUNCH_CHECK("paste_back_u8");
     return FUSG_OK;
 }
-extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) { return fusg::plan_dispatch(paste_back_u8_impl, stream, net, masks, geom, frame); }
+extern "C" int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream) {
+    return fusg::plan_dispatch(paste_layers_u8_impl, stream, net, masks, geom, (const fusg_tensor*)nullptr, (const int32_t*)nullptr, frame);
+}
+extern "C" int fusg_paste_layers_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* rect,
+                                    const int32_t* rect_geom, const fusg_tensor* frame, void* stream) {
+    return fusg::plan_dispatch(paste_layers_u8_impl, stream, net, masks, geom, rect, rect_geom, frame);
+}
 
 struct Norm3 { float m[3], s[3]; int has; };      // mode 1's mean / std, captured by value (host arrays at the ABI)
 static int crop_resize_impl(const fusg_tensor* src, const int32_t* geom, const fusg_tensor* dst, int32_t mode, Norm3 nm, void* stream) {

@@ -354,7 +354,12 @@ class VehiclePipeline:
         CAD model's keypoints); 'focals' / 'centers' [2] (host); optional 'background' uint8 [H, W, 3] (default: the frame).
         What the reference computes BETWEEN the pose fit and the plane warp - rendering the posed CAD model into sketches,
         masks and plane corner points with Open3D (warp_learn/vehicle_utils.py) - is out of scope: those
-        are inputs here, and the pose is an output for that renderer.
+        are inputs here, and the pose is an output for that renderer.  A pipeline built with inpaint=True also takes
+        'inpaint' = {'boxes' host int [V, 4] (bbox_new_img: the 1.3x detector box clipped to the frame), 'img' float32
+        [V, 3, R, R], 'gray' / 'edge' / 'mask' float32 [V, 1, R, R] in [0, 1]} - what create_inpaint_inputs_shape hands
+        EdgeConnect (utils/inpaint_utils.py:35-58: Mask R-CNN mask, dilation, Canny - host steps, out of scope) - runs
+        EdgeModel -> InpaintingModel -> merge as a fourth branch (:124-129), composites every vehicle's inpainted box under
+        its pasted crop in the reference's per-vehicle order (:130-145) and returns 'inpaint_u8' [V, R, R, 3] as well.
 
         replay=True issues the three networks as ONE recorded-plan replay (`CompiledPass`, recorded on the first frame with
         this many vehicles and kept per vehicle count) instead of ~370 launches from Python: at 8 vehicles per frame the
@@ -450,7 +455,11 @@ class VehiclePipeline:
         V, R = bboxes.shape[0], 256
         seeds = scene.get("vehicle_seeds")
         with torch.cuda.device(dev):
-            replay = replay and not self.inpaint and ops.RECORDER is None
+            replay = replay and ops.RECORDER is None
+            inp = scene.get("inpaint") if self.inpaint else None
+            if self.inpaint and inp is None:
+                raise ValueError("run_frame: this pipeline was built with inpaint=True; the scene needs 'inpaint' = "
+                                 "{'boxes' [V, 4], 'img' [V, 3, R, R], 'gray' / 'edge' / 'mask' [V, 1, R, R]}")
             cps = self.__dict__.setdefault("_frame_plans", {})
             cp = cps.get((V, ops.PRECISION)) if replay else None
             if cp is not None and [n.generation for n in self._nets] != cp.generations:
@@ -470,12 +479,15 @@ class VehiclePipeline:
                                          out=(tgt["vu_x"], tgt["vu_y"]) if tgt else None)       # :203-228
             # ---- the three networks: the crop pass of `run` (three stream branches), eagerly or as one plan replay
             nets_in = {"hg_x": hg_x, "icn_x": icn_x, "vu_x": vu_x, "vu_y": vu_y}
+            if inp is not None:                                   # :121: create_inpaint_inputs_shape's four tensors, given
+                nets_in.update(ec_img=inp["img"], ec_gray=inp["gray"], ec_edge=inp["edge"], ec_mask=inp["mask"])
             if replay:
                 if cp is None:
                     cp = cps[(V, ops.PRECISION)] = CompiledPass(self, nets_in, seeds)
                 out = dict(cp._issue(nets_in, seeds))
-                out["vunet_u8"] = out["vunet_u8"].clone()        # the plan's buffers belong to its next replay
-                out["kp_idx"] = out["kp_idx"].clone()
+                for k in ("vunet_u8", "kp_idx", "inpaint_u8"):    # the plan's buffers belong to its next replay
+                    if k in out:
+                        out[k] = out[k].clone()
             else:
                 out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
             # ---- keypoints -> frame pixels -> pose fit; Lab -> BGR; ordered paste of every vehicle into the two frames
@@ -484,9 +496,15 @@ class VehiclePipeline:
             out["kp_xy"] = fo.keypoints_to_frame(out["kp_idx"], geom_box, (R // 4, R // 4))   # :95-97 (64 x 64 heat-maps)
             out["_pose_raw"] = cpc_fit_device(f32(scene["focals"]), f32(scene["centers"]), out["kp_xy"], kp3d)   # :104-105
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
-            back = scene.get("background", frame)
-            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"])       # :184-198
-            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"])   # :236-250
+            if inp is not None:                                   # :133-143: the running composite starts from the frame
+                rows = [[int(b[0]), int(b[1]), int(b[2]), int(b[3]), 0, 0, 0, 0] for b in np.asarray(inp["boxes"]).reshape(-1, 4)]
+                box = dict(box_images=out["inpaint_u8"], box_geom=ops.h2d(rows, dev, torch.int32))
+                back = frame
+            else:
+                box = {}
+                back = scene.get("background", frame)
+            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"], **box)       # :184-198
+            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"], **box)   # :236-250
             out["geom"] = geom
         return out
 
@@ -650,7 +668,7 @@ def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int =
     return {k: t.to(device) for k, t in b.items()}
 
 
-def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 0) -> Dict:
+def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 0, inpaint: bool = False) -> Dict:
     """A synthetic frame for `VehiclePipeline.run_frame`: smooth random texture, `vehicles` detector boxes, and per
     vehicle what the reference's renderer would hand over - an elliptical sketch (normal-map colours) with its mask,
     five texture-plane quadrilaterals (corner points before and after a small pose change, visibilities) and the planes
@@ -704,7 +722,18 @@ def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 
         planes.append(pu.fill_planes(frame, src_kp[-1]))
         kp3d.append((g.uniform(-1, 1, (12, 3)) * np.array([0.9, 0.5, 2.0]) * 5).astype(np.float32))
     t8 = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)   # noqa: E731
-    return {"frame": frame, "bboxes": np.asarray(bboxes, dtype=np.int64), "masks": t8(masks), "src_sketch": t8(sk_src),
+    extra = {}
+    if inpaint:                                                               # EdgeConnect's inputs per vehicle (given, see run_frame)
+        from .synth import synth_inputs
+        e = synth_inputs("edge", vehicles, 256, seed)
+        boxes = []
+        for x0, y0, x1, y1 in bboxes:                                         # the 1.3x box, clipped to the frame
+            cx, cy, bw, bh = (x0 + x1) / 2, (y0 + y1) / 2, 1.3 * (x1 - x0), 1.3 * (y1 - y0)
+            bx0, by0 = max(0, int(cx - bw / 2)), max(0, int(cy - bh / 2))
+            boxes.append([bx0, by0, max(bx0 + 2, min(W - 1, int(cx + bw / 2))), max(by0 + 2, min(H - 1, int(cy + bh / 2)))])
+        extra["inpaint"] = {"boxes": np.asarray(boxes, dtype=np.int64), "img": e["img"].to(dev), "gray": e["gray"].to(dev),
+                            "edge": e["edge"].to(dev), "mask": e["mask"].to(dev)}
+    return {**extra, "frame": frame, "bboxes": np.asarray(bboxes, dtype=np.int64), "masks": t8(masks), "src_sketch": t8(sk_src),
             "dst_sketch": t8(sk_dst), "src_planes": torch.stack(planes), "src_kp": src_kp, "dst_kp": dst_kp,
             "src_vis": np.stack(src_vis), "dst_vis": np.stack(dst_vis), "kp3d": np.stack(kp3d),
             "focals": np.array([1.1 * W, 1.1 * W], np.float32), "centers": np.array([W / 2, H / 2], np.float32)}

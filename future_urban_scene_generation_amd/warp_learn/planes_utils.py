@@ -488,13 +488,22 @@ def to_image_device(x: torch.Tensor, from_LAB: bool) -> torch.Tensor:
     return lab2bgr(u8) if from_LAB else u8
 
 
-def paste_back_device(frame: torch.Tensor, net_images: torch.Tensor, geom: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
-    """paste_back with device geometry rows (int32 [V, 8]) and device masks (uint8 [V, H, W]); returns a new frame tensor."""
+def paste_back_device(frame: torch.Tensor, net_images: torch.Tensor, geom: torch.Tensor, masks: torch.Tensor,
+                      box_images: Optional[torch.Tensor] = None, box_geom: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """paste_back with device geometry rows (int32 [V, 8]) and device masks (uint8 [V, H, W]); returns a new frame tensor.
+    box_images uint8 [V, h, w, 3] + box_geom int32 [V, 8] (x0, y0, x1, y1, ...): the --inpaint form - every vehicle first
+    writes its inpainted box image, resized to its rectangle, then its masked network image (fusg_paste_layers_u8)."""
     fr = frame.contiguous().clone()
     V, H, W = masks.shape
     with torch.cuda.device(fr.device):
-        L.check(L.lib().fusg_paste_back_u8(C.byref(_u8desc(net_images.contiguous())), C.byref(ops.desc(masks.contiguous().view(V, 1, H, W))),
-                                           geom.data_ptr(), C.byref(_u8desc(fr[None])), ops.stream_ptr()), "paste_back_u8")
+        if box_images is None:
+            L.check(L.lib().fusg_paste_back_u8(C.byref(_u8desc(net_images.contiguous())), C.byref(ops.desc(masks.contiguous().view(V, 1, H, W))),
+                                               geom.data_ptr(), C.byref(_u8desc(fr[None])), ops.stream_ptr()), "paste_back_u8")
+        else:
+            assert box_geom is not None and box_geom.dtype == torch.int32 and tuple(box_geom.shape) == (V, 8) and box_images.shape[0] == V
+            L.check(L.lib().fusg_paste_layers_u8(C.byref(_u8desc(net_images.contiguous())), C.byref(ops.desc(masks.contiguous().view(V, 1, H, W))),
+                                                 geom.data_ptr(), C.byref(_u8desc(box_images.contiguous())), box_geom.contiguous().data_ptr(),
+                                                 C.byref(_u8desc(fr[None])), ops.stream_ptr()), "paste_layers_u8")
     return fr
 
 

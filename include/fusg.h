@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 107
+#define FUSG_VERSION 108
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -360,6 +360,13 @@ int fusg_lab2bgr_u8(const fusg_tensor* src, const fusg_tensor* dst, void* stream
  * vehicle's image resized (cv2.resize INTER_LINEAR) to its crop, padding removed, placed at crop_xy_min - or 0 where
  * the pixel lies outside that rectangle; masks u8 [V, 1, H, W] (non-zero = paste), geom as in fusg_icn_inputs. */
 int fusg_paste_back_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* frame, void* stream);
+/* The same with --inpaint (trajectory_inference.py:107-145): vehicle v first writes its inpainted box image rect[v] (u8,
+ * EdgeConnect's merged output * 255, :126-129), resized (cv2.resize INTER_LINEAR, :130-131) to the rectangle rect_geom[v] =
+ * (x0, y0, x1, y1, -, -, -, -) = bbox_new_img, unmasked into the running composite (:140-143), then pastes its masked
+ * network image as above (:184-198); vehicles in index order, the last layer covering a pixel wins.  rect / rect_geom
+ * (DEVICE int32 [V][8]) both NULL = fusg_paste_back_u8. */
+int fusg_paste_layers_u8(const fusg_tensor* net, const fusg_tensor* masks, const int32_t* geom, const fusg_tensor* rect,
+                         const int32_t* rect_geom, const fusg_tensor* frame, void* stream);
 
 /* ---- frame-chain glue (pipeline.VehiclePipeline.run_frame): the uint8 -> float steps between the frame and the networks */
 /* square_crop_from_bbox (utils/crop_utils.py:4-52) + cv2.resize INTER_LINEAR for V windows: src u8 HWC [1] (every

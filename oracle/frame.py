@@ -1,5 +1,5 @@
 """Oracle: one frame's vehicles through the reference's per-vehicle chain (trajectory_inference.py:55-250, first frame,
---inpaint off), vehicle by vehicle like the reference, on the CPU: the counterpart of
+--inpaint off, or on when the scene carries EdgeConnect's inputs), vehicle by vehicle like the reference, on the CPU: the counterpart of
 future_urban_scene_generation_amd.pipeline.VehiclePipeline.run_frame.  Tests only.
 
 Pinned parts: the three networks, get_maxima, to_image's quantiser (oracle/*.py, bit-equal to the imported reference)
@@ -17,6 +17,7 @@ import torch
 from . import cv_host as cv
 from . import pnp
 from .host import to_image_u8, to_tensor_pm1
+from .edgeconnect import edge_model_forward, inpaint_model_forward
 from .hourglass import get_maxima, heatmap_argmax, hourglass_forward
 from .icn import icn_forward
 from .vunet import vunet_forward
@@ -44,10 +45,13 @@ def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dic
     (numpy), plus the intermediates the chain test compares: 'hg_x', 'icn_x', 'vu_x', 'vu_y', 'warped'."""
     frame = scene["frame"]
     H, W = frame.shape[:2]
-    back = scene.get("background", frame)
+    inp = scene.get("inpaint") if "edge" in state_dicts else None
+    back = frame if inp is not None else scene.get("background", frame)          # :135-136: the composite starts from the frame
     out_icn, out_vu = back.copy(), back.copy()
     V = len(scene["bboxes"])
     res_ = {k: [] for k in ("kp_idx", "kp_xy", "pose", "icn_u8", "vunet_u8", "hg_x", "icn_x", "vu_x", "vu_y", "warped", "geom")}
+    if inp is not None:
+        res_["inpaint_u8"] = []
     seeds = scene.get("vehicle_seeds")
     for v in range(V):
         bbox = [int(t) for t in scene["bboxes"][v]]
@@ -61,6 +65,17 @@ def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dic
         kp[:, 1] = kp[:, 1] * (y1 - y0) + y0 - pb[1]
         kp32 = kp.astype(np.float32)
         pose = pnp.cpc_rodr_4_angles(scene["focals"], scene["centers"], kp32, scene["kp3d"][v])[:3]   # :104-105
+        if inp is not None:                                                                   # :121-143, inputs given (see run_frame)
+            t = lambda k: torch.from_numpy(np.ascontiguousarray(inp[k][v:v + 1]))              # noqa: E731
+            e = edge_model_forward(state_dicts["edge"], t("gray"), t("edge"), t("mask"))       # :124
+            p = inpaint_model_forward(state_dicts["inpaint"], t("img"), e, t("mask"))          # :125
+            merged = (p * t("mask") + t("img") * (1 - t("mask"))) * 255.0                      # :126-127
+            u8 = merged.permute(0, 2, 3, 1)[0].numpy().astype(np.uint8)                        # :128-129 (truncation)
+            bx0, by0, bx1, by1 = (int(q) for q in inp["boxes"][v])
+            img_output = cv.resize_linear_u8(u8, (bx1 - bx0, by1 - by0))                       # [cv] :130-131, dsize = (w, h)
+            out_icn[by0:by1, bx0:bx1] = img_output                                             # :140-143
+            out_vu[by0:by1, bx0:bx1] = img_output
+            res_["inpaint_u8"].append(u8)
         off = int(res * 0.1)                                                                  # vehicle_utils.py:49-52
         central = cv.resize_linear_u8(img_bbox[res // 2 - off:res // 2 + off, res // 2 - off:res // 2 + off].copy(), (res, res))
         warped, _ = cv.warp_unwarp_planes(scene["src_planes"][v], scene["src_kp"][v], scene["dst_kp"][v],
