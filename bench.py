@@ -537,47 +537,47 @@ def main():
                               "vehicle_clips_per_s": round(V / cdt, 2), "frames_per_s": round(V * F / cdt, 1),
                               "range_status_raised": bool(bad)}
         del clip
+    if rank == 0 and world == 1 and not args.no_clip and args.res == 256:
         # secondary figure: frame mode = the chained per-frame driver (VehiclePipeline.run_frame: detector boxes -> box
         # crops -> hourglass -> argmax -> pose fit, plane warps -> ICN inputs -> ICN -> Lab image, VUnet inputs -> VUnet,
         # resize-back + ordered paste of every vehicle), 8 vehicles on a 720 x 1280 frame, everything device-resident;
         # the host part per frame = the 2 x 5 homography fits per vehicle and the pose fit's 4 x 7-number epilogue
-        if args.res == 256:
-            from future_urban_scene_generation_amd.pipeline import synth_frame
-            FV = 8
-            scene = synth_frame(FV, (720, 1280), dev, seed=3, inpaint=bool(args.inpaint))
-            scene["vehicle_seeds"] = list(range(FV))
-            fms = {}
-            for mode, rep in (("eager", False), ("replay", True)):
-                pipe.run_frame(scene, replay=rep)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    pipe.run_frame(scene, replay=rep)
-                torch.cuda.synchronize()
-                fms[mode] = (time.perf_counter() - t1) / 5
-            # a sequence of frames (two scenes alternating), one frame in flight while the next is issued: run_frames
-            scene2 = synth_frame(FV, (720, 1280), dev, seed=4, inpaint=bool(args.inpaint))
-            scene2["vehicle_seeds"] = list(range(100, 100 + FV))
-            for _ in pipe.run_frames([scene, scene2, scene]):
-                pass
+        from future_urban_scene_generation_amd.pipeline import synth_frame
+        FV = 8
+        scene = synth_frame(FV, (720, 1280), dev, seed=3, inpaint=bool(args.inpaint))
+        scene["vehicle_seeds"] = list(range(FV))
+        fms = {}
+        for mode, rep in (("eager", False), ("replay", True)):
+            pipe.run_frame(scene, replay=rep)
             torch.cuda.synchronize()
-            NF = 12
             t1 = time.perf_counter()
-            for _ in pipe.run_frames([scene, scene2] * (NF // 2)):
-                pass
+            for _ in range(5):
+                pipe.run_frame(scene, replay=rep)
             torch.cuda.synchronize()
-            fdt = (time.perf_counter() - t1) / NF
-            extra["frame_mode"] = {"vehicles": FV, "frame": "720x1280", "ms_per_frame": round(fdt * 1e3, 3),
-                                   "vehicles_per_s": round(FV / fdt, 2),
-                                   "ms_per_frame_one_at_a_time": round(fms["replay"] * 1e3, 3),
-                                   "ms_per_frame_one_at_a_time_eager": round(fms["eager"] * 1e3, 3),
-                                   "issue": "run_frames over 12 frames: networks as one recorded-plan replay, frame i+1 issued "
-                                            "before frame i's pose / range status are read back (pinned, one event per frame); "
-                                            "run_frame (one synchronous frame at a time) beside it",
-                                   "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
-                                               + ("EdgeConnect on every vehicle's box + its resize-back under the pasted crop, " if args.inpaint else "")
-                                               + "paste-back of both composited frames; range check per frame"}
-            del scene, scene2
+            fms[mode] = (time.perf_counter() - t1) / 5
+        # a sequence of frames (two scenes alternating), one frame in flight while the next is issued: run_frames
+        scene2 = synth_frame(FV, (720, 1280), dev, seed=4, inpaint=bool(args.inpaint))
+        scene2["vehicle_seeds"] = list(range(100, 100 + FV))
+        for _ in pipe.run_frames([scene, scene2, scene]):
+            pass
+        torch.cuda.synchronize()
+        NF = 12
+        t1 = time.perf_counter()
+        for _ in pipe.run_frames([scene, scene2] * (NF // 2)):
+            pass
+        torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t1) / NF
+        extra["frame_mode"] = {"vehicles": FV, "frame": "720x1280", "ms_per_frame": round(fdt * 1e3, 3),
+                               "vehicles_per_s": round(FV / fdt, 2),
+                               "ms_per_frame_one_at_a_time": round(fms["replay"] * 1e3, 3),
+                               "ms_per_frame_one_at_a_time_eager": round(fms["eager"] * 1e3, 3),
+                               "issue": "run_frames over 12 frames: networks as one recorded-plan replay, frame i+1 issued "
+                                        "before frame i's pose / range status are read back (pinned, one event per frame); "
+                                        "run_frame (one synchronous frame at a time) beside it",
+                               "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
+                                           + ("EdgeConnect on every vehicle's box + its resize-back under the pasted crop, " if args.inpaint else "")
+                                           + "paste-back of both composited frames; range check per frame"}
+        del scene, scene2
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, quality = cpu_baseline_leg(args, batch, pipe, torch)
