@@ -68,7 +68,14 @@ struct HaloK {
     int qtdy[4][4], qtdx[4][4]; // halo pixel offset (rows, columns) of each (quadrant, local tap)
     int nt32;                   // cout_pad / 32
     int touch_off;              // byte offset of the L2-touch dummy region in dynamic LDS (conv_kernel.h, l2_touch)
+    // Reciprocals of the prologue's divisors (launch_halo fills them): n / d == umulhi(n, ceil(2^32 / d)) for every n the
+    // kernel divides (n * d < 2^32, checked on the host, which refuses the launch otherwise; 0 = the divisor is 1).  An integer division costs ~25 VALU
+    // instructions on gfx950 and the prologue had 3 + NI of them per thread - a sixth of all VALU work of a 32-column
+    // launch, which is VALU-issue-bound (profiles/r03_pmc_narrow_layers.txt).
+    unsigned m_hw, m_nt, m_tpi, m_tx;
 };
+
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }     // m == 0: d == 1
 
 __device__ __forceinline__ void pix_offsets_yx(const ConvK& p, int b, int oy, int ox, PixOff& o) {
     long Y, X, cq = 0;
@@ -126,12 +133,12 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int nt = tile % p.NT;
-    const int mt = tile / p.NT;
+    const int mt = fdiv(tile, hk.m_nt);
+    const int nt = tile - mt * p.NT;
     int b, t2;
     if (hk.tile_list) { b = mt / hk.tile_count; t2 = hk.tile_list[mt - b * hk.tile_count]; }
-    else { b = mt / hk.tiles_per_img; t2 = mt - b * hk.tiles_per_img; }
-    const int ty = t2 / hk.tiles_x, tx = t2 - ty * hk.tiles_x;
+    else { b = fdiv(mt, hk.m_tpi); t2 = mt - b * hk.tiles_per_img; }
+    const int ty = fdiv(t2, hk.m_tx), tx = t2 - ty * hk.tiles_x;
     const int oy0 = ty * PR, ox0 = tx * 16;
 
     // ---- halo items of this thread: pixel index inside the source image + validity (same for every chunk)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         hoff[j] = 0;
         if (pix < HP) {
             hexist |= 1u << j;
-            const int hy = pix / hk.HW, hx = pix - hy * hk.HW;
+            const int hy = fdiv(pix, hk.m_hw), hx = pix - hy * hk.HW;
             hoff[j] = hy * hk.RP + hx * HPITCH + ((((kc >> 1) ^ (((hx >> 2) & 1) << 1)) << 3) | ((kc & 1) << 2));
             int vy = oy0 - hk.pad_h + hy, vx = ox0 - hk.pad_w + hx;
             bool ok = true;
@@ -559,6 +566,17 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
     HaloK kk = k;
     kk.RP = halo_row_pitch(k.HW);
     kk.touch_off = touch_off;
+    bool fits = true;
+    auto magic = [&fits](long nmax, int d) -> unsigned {       // exact for n <= nmax when nmax * d < 2^32; 0 for d == 1
+        if (d < 1 || nmax * d >= (1L << 32)) fits = false;
+        return d < 2 ? 0u : (unsigned)(((1UL << 32) + (unsigned long)d - 1) / (unsigned long)d);
+    };
+    const long ntiles = (long)grid.x;
+    kk.m_hw = magic(256L * 10 + 255, k.HW);                    // pix <= (255 + 256 * (NI - 1)) >> 3, bounded loosely
+    kk.m_nt = magic(ntiles, k.c.NT);
+    kk.m_tpi = magic(ntiles, k.tiles_per_img);
+    kk.m_tx = magic((long)k.tiles_per_img, k.tiles_x);
+    if (!fits) return hipErrorInvalidValue;                    // > 2^32 / d tiles: not a shape this kernel is dispatched for
     void* args[] = {(void*)&kk};
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }

@@ -14,8 +14,9 @@ from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_fr
 
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
-pipe = VehiclePipeline(dev)
-scene = synth_frame(8, (720, 1280), dev, seed=3)
+INP = len(sys.argv) > 1 and sys.argv[1] == "inpaint"      # the --inpaint branch (EdgeConnect as a fourth network)
+pipe = VehiclePipeline(dev, inpaint=INP)
+scene = synth_frame(8, (720, 1280), dev, seed=3, inpaint=INP)
 scene["vehicle_seeds"] = list(range(8))
 for _ in pipe.run_frames([scene] * 3):
     pass
@@ -25,10 +26,16 @@ for _ in pipe.run_frames([scene] * 10):
     pass
 torch.cuda.synchronize()
 print("ms per frame (run_frames)", (time.perf_counter() - t0) / 10 * 1e3)
+t0 = time.perf_counter()
+for _ in range(10):
+    pipe._issue_frame(scene, True)
+th = (time.perf_counter() - t0) / 10 * 1e3
+torch.cuda.synchronize()
+print("host ms to issue a frame %.3f; with the GPU drained after it %.3f" % (th, (time.perf_counter() - t0) / 10 * 1e3))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):
     pipe._issue_frame(scene, True)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

@@ -15,10 +15,11 @@ V = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
-pipe = VehiclePipeline(dev)
+INP = len(sys.argv) > 3 and sys.argv[3] == "inpaint"
+pipe = VehiclePipeline(dev, inpaint=INP)
 scenes = []
 for sd in (3, 4):
-    sc = synth_frame(V, (720, 1280), dev, seed=sd)
+    sc = synth_frame(V, (720, 1280), dev, seed=sd, inpaint=INP)
     sc["vehicle_seeds"] = list(range(sd * 100, sd * 100 + V))
     scenes.append(sc)
 for _ in range(3):

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/r03r
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -o frame --output-format csv -- python3 $R/tools/frame_trace.py 8 12 > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/prof -o frame --output-format csv -- python3 $R/tools/frame_trace.py 8 12 $1 > $out/trace.log 2>&1
 grep "ms per" $out/trace.log
 f=$(find $out/prof -name '*kernel_stats.csv' | head -1)
 cp $f $out/frame_kernel_stats.csv
