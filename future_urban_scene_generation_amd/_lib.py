@@ -101,6 +101,7 @@ _SIGS = {
     "fusg_to_image_u8": (C.c_int, [_TP, _TP, C.c_void_p]),
     "fusg_merge_u8": (C.c_int, [_TP, _TP, _TP, _TP, C.c_void_p]),
     "fusg_warp_perspective_u8": (C.c_int, [_TP, C.c_void_p, _TP, C.c_void_p]),
+    "fusg_warp_perspective_indexed_u8": (C.c_int, [_TP, C.c_void_p, C.c_void_p, C.c_int32, _TP, C.c_void_p]),
     "fusg_fill_poly_planes_u8": (C.c_int, [_TP, C.c_void_p, C.c_void_p, C.c_int32, _TP, C.c_void_p]),
     "fusg_icn_inputs": (C.c_int, [_TP, _TP, _TP, C.c_void_p, _TP, C.c_void_p]),
     "fusg_lab2bgr_u8": (C.c_int, [_TP, _TP, C.c_void_p]),

@@ -361,10 +361,14 @@ def warp_planes_batch(src_planes: torch.Tensor, jobs_per_vehicle) -> torch.Tenso
             src_idx.append(v * P + i)
             dst_idx.append(v * P + j)
             Hs.append(H12)
-    if Hs:
-        si = ops.h2d(src_idx, flat.device, torch.int64)
-        w1 = warp_perspective(flat[si], Hs, (W, H))
-        warped[ops.h2d(dst_idx, flat.device, torch.int64)] = w1
+    if Hs:                                                        # every job reads its plane and writes its slot in place
+        flat = flat.contiguous()
+        minv = np.stack([np.linalg.inv(np.asarray(h, dtype=np.float64)) for h in Hs]).reshape(len(Hs), 9)
+        minv_d = ops.h2d(minv, flat.device)
+        index = ops.h2d(np.stack([src_idx, dst_idx], 1).astype(np.int32), flat.device)
+        with torch.cuda.device(flat.device):
+            L.check(L.lib().fusg_warp_perspective_indexed_u8(C.byref(_u8desc(flat)), minv_d.data_ptr(), index.data_ptr(), len(Hs),
+                                                             C.byref(_u8desc(warped)), ops.stream_ptr()), "warp_perspective_indexed_u8")
     return warped.view(V, P, H, W, 3)
 
 

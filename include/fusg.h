@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 108
+#define FUSG_VERSION 109
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -341,6 +341,12 @@ int fusg_merge_u8(const fusg_tensor* out, const fusg_tensor* img, const fusg_ten
  * (OpenCV inverts H on the host too).  Coordinates in double, rounded to 1/32 pixel, 15-bit bilinear weights,
  * (sum + 2^14) >> 15.  src and dst may differ in h, w. */
 int fusg_warp_perspective_u8(const fusg_tensor* src, const double* minv, const fusg_tensor* dst, void* stream);
+/* The same for a list of jobs inside two image stacks (every plane of every vehicle of a frame in one launch,
+ * pipeline.VehiclePipeline.run_frame): job k warps image index[2k] of src with minv[k] into image index[2k + 1] of dst;
+ * index = DEVICE int32 [jobs][2]; images of dst no job names are left untouched (the caller zero-fills them:
+ * planes_utils.py:57 starts from zeros). */
+int fusg_warp_perspective_indexed_u8(const fusg_tensor* src, const double* minv, const int32_t* index, int32_t jobs,
+                                     const fusg_tensor* dst, void* stream);
 /* get_planes (warp_learn/planes_utils.py:11-37): dst[p] = frame * fillPoly(polygon p) for up to 8 polygons of up
  * to 8 int32 vertices.  pts_xy [nplanes][8][2] (x, y) and nverts [nplanes] are HOST arrays (read before return). */
 int fusg_fill_poly_planes_u8(const fusg_tensor* frame, const int32_t* pts_xy, const int32_t* nverts, int32_t nplanes,

@@ -73,6 +73,18 @@ def test_mask_bbox_geom_and_keypoints_to_frame():
         (x0, y0, x1, y1), pb, pa = C.square_crop_geometry((H, W), bb)
         assert geom[v].tolist() == [x0, y0, x1, y1, pb[0], pb[1], pa[0], pa[1]], v
     assert geom[3].tolist() == [0] * 8                                  # empty mask
+    g = np.random.default_rng(2)                                        # 16-byte row scans: sparse pixels, aligned and ragged widths
+    for Wd in (160, 173, 1280):
+        m2 = np.zeros((6, 37, Wd), np.uint8)
+        for v in range(6):
+            for _ in range(int(g.integers(1, 5))):
+                m2[v, int(g.integers(0, 37)), int(g.integers(0, Wd))] = int(g.integers(1, 256))
+        m2[5] = 0
+        m2[5, 36, Wd - 1] = 1
+        bb2 = fo.mask_bbox_geom(_d(m2))[0].cpu().numpy()
+        for v in range(6):
+            ys, xs = np.nonzero(m2[v])
+            assert bb2[v].tolist() == [int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())], (Wd, v)
     idx = torch.tensor([[0, 63, 64 * 63, 64 * 64 - 1, 64 * 10 + 7] + [5] * 7] * 2, dtype=torch.int32, device=DEV)
     g2 = fo.box_geometry((H, W), [(-20, 10, 60, 70), (30, 20, 140, 95)], DEV)
     kp = fo.keypoints_to_frame(idx, g2, (64, 64)).cpu().numpy()
