@@ -113,6 +113,22 @@ def load_schema(net: str):
     return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
 
 
+PER_VEHICLE_KEYS = ("bboxes", "masks", "src_sketch", "dst_sketch", "src_planes", "src_kp", "dst_kp", "src_vis", "dst_vis", "kp3d",
+                    "vehicle_seeds")
+
+
+def slice_scene(scene: Dict, lo: int, hi: int) -> Dict:
+    """The scene of `run_frame` restricted to vehicles [lo, hi): per-vehicle entries sliced (views, nothing copied), frame-level
+    entries (frame, background, focals, centers) shared."""
+    out = dict(scene)
+    for k in PER_VEHICLE_KEYS:
+        if scene.get(k) is not None:
+            out[k] = scene[k][lo:hi]
+    if scene.get("inpaint") is not None:
+        out["inpaint"] = {k: v[lo:hi] for k, v in scene["inpaint"].items()}
+    return out
+
+
 class VehiclePipeline:
     """Holds the five networks on one device and runs batches of crops through them."""
 
@@ -129,6 +145,7 @@ class VehiclePipeline:
         from .warp_learn.models import G_Resnet
         self.device = torch.device(device)
         self.inpaint = inpaint
+        self.group = group
         if broadcast_src is not None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -365,10 +382,33 @@ class VehiclePipeline:
         this many vehicles and kept per vehicle count) instead of ~370 launches from Python: at 8 vehicles per frame the
         interpreter, not the GPU, bounds the eager form.
 
+        With an initialised process group of more than one rank the frame's vehicles are sharded over the ranks (every rank
+        passes the same scene; rank 0 returns the result, the others None; scene['shard'] = False keeps a rank on its own).
+
         Returns 'kp_idx' int32 [V, 12], 'kp_xy' float32 [V, 12, 2], 'pose' = list of (error, rvec [3, 1], tvec [3, 1]),
         'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8]."""
         rng = torch.get_rng_state() if check == "sync" else None
-        out = self._guarded(self._run_frame, (scene, replay), check, rng)
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 and scene.get("shard", True):
+            # One frame's vehicles over the ranks (SURVEY.md 8e, BASELINE configs[3]: 64 vehicles of a frame, 8 shards of 8):
+            # every rank holds the scene and renders vehicles shard_range(V, rank, world); the uint8 crops, keypoint indices
+            # and crop rows travel to rank 0 (gather_in_order: five small messages per frame, no other exchange), which fits
+            # the poses and pastes in vehicle order.  The range guard stays local to a rank's own vehicles - it runs
+            # before the first collective, so a rank that redoes its shard in fp32 cannot desynchronise the gathers.
+            rank = dist.get_rank(self.group)
+            V = len(scene["bboxes"])
+            lo, hi = shard_range(V, rank, world)
+            local = self._guarded(self._frame_local, (slice_scene(scene, lo, hi), replay), check, rng)
+            full = {}
+            for k in ("kp_idx", "icn_u8", "vunet_u8", "geom") + (("inpaint_u8",) if self.inpaint else ()):
+                g = gather_in_order(local[k].contiguous(), V, self.group)
+                full[k] = None if g is None else g.to(self.device)
+            if rank != 0:
+                return None
+            out = self._frame_finish(scene, full)
+        else:
+            out = self._guarded(self._run_frame, (scene, replay), check, rng)
         # the reference's host epilogue of the pose fit (argmin over the four starts, sign flip): 4 x 7 numbers per vehicle
         from .utils.pnp_utils import select_and_flip
         rv, tv, er = (t.cpu().numpy() for t in out.pop("_pose_raw"))
@@ -383,7 +423,11 @@ class VehiclePipeline:
         waits for frame i only.  A generator: yields one `run_frame`-shaped dict per scene, in order; every tensor in it
         is the caller's (nothing aliases a later frame's buffers).  A frame whose split-fp16 range status is raised is
         redone in exact fp32 before it is yielded, with the RNG state it was issued under."""
-        from . import ops
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for scene in scenes:                                  # sharded frames: one collective phase per frame, not pipelined
+                yield self.run_frame(scene, replay=replay)
+            return
         pending = None
         for scene in scenes:
             ticket = self._issue_frame(scene, replay)
@@ -440,13 +484,18 @@ class VehiclePipeline:
         out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
         return out
 
-    @torch.no_grad()
     def _run_frame(self, scene, replay=False):
+        """One rank, every vehicle: the per-vehicle part, then the frame-level part."""
+        return self._frame_finish(scene, self._frame_local(scene, replay))
+
+    @torch.no_grad()
+    def _frame_local(self, scene, replay=False):
+        """The per-vehicle part of a frame for the vehicles `scene` lists (all of them, or one rank's shard): glue, the
+        networks, Lab -> BGR.  Returns 'kp_idx', 'icn_u8' (BGR), 'vunet_u8', 'geom' (+ 'inpaint_u8'), device tensors."""
         import numpy as np
 
         from . import frame_ops as fo
         from . import ops
-        from .utils.pnp_utils import cpc_fit_device
         from .warp_learn import planes_utils as pu
         dev = self.device
         frame = scene["frame"]
@@ -455,11 +504,18 @@ class VehiclePipeline:
         V, R = bboxes.shape[0], 256
         seeds = scene.get("vehicle_seeds")
         with torch.cuda.device(dev):
-            replay = replay and ops.RECORDER is None
             inp = scene.get("inpaint") if self.inpaint else None
             if self.inpaint and inp is None:
                 raise ValueError("run_frame: this pipeline was built with inpaint=True; the scene needs 'inpaint' = "
                                  "{'boxes' [V, 4], 'img' [V, 3, R, R], 'gray' / 'edge' / 'mask' [V, 1, R, R]}")
+            if V == 0:                                            # no vehicle in the frame (or an empty shard)
+                e8 = lambda: torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)   # noqa: E731
+                out = {"kp_idx": torch.empty((0, 12), dtype=torch.int32, device=dev), "icn_u8": e8(), "vunet_u8": e8(),
+                       "geom": torch.empty((0, 8), dtype=torch.int32, device=dev)}
+                if inp is not None:
+                    out["inpaint_u8"] = e8()
+                return out
+            replay = replay and ops.RECORDER is None
             cps = self.__dict__.setdefault("_frame_plans", {})
             cp = cps.get((V, ops.PRECISION)) if replay else None
             if cp is not None and [n.generation for n in self._nets] != cp.generations:
@@ -490,22 +546,45 @@ class VehiclePipeline:
                         out[k] = out[k].clone()
             else:
                 out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
-            # ---- keypoints -> frame pixels -> pose fit; Lab -> BGR; ordered paste of every vehicle into the two frames
+            out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
+            out["geom"] = geom
+        return out
+
+    @torch.no_grad()
+    def _frame_finish(self, scene, out):
+        """The frame-level part, on the rank that holds every vehicle's crops (`out`: _frame_local's dict for ALL the
+        scene's vehicles, in vehicle order): keypoints -> frame pixels -> pose fit, ordered paste into the two frames."""
+        import numpy as np
+
+        from . import frame_ops as fo
+        from . import ops
+        from .utils.pnp_utils import cpc_fit_device
+        from .warp_learn import planes_utils as pu
+        dev = self.device
+        frame = scene["frame"]
+        H, W, _ = frame.shape
+        bboxes = np.asarray(scene["bboxes"]).reshape(-1, 4)
+        V, R = bboxes.shape[0], 256
+        inp = scene.get("inpaint") if self.inpaint else None
+        out = dict(out)
+        with torch.cuda.device(dev):
+            back = frame if inp is not None else scene.get("background", frame)   # :133-143: with --inpaint the composite starts from the frame
+            if V == 0:
+                out["kp_xy"] = torch.empty((0, 12, 2), dtype=torch.float32, device=dev)
+                out["_pose_raw"] = tuple(torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((0, 4, 3), (0, 4, 3), (0, 4)))
+                out["frame_icn"], out["frame_vunet"] = back.clone(), back.clone()
+                return out
             f32 = lambda a: ops.h2d(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2))), dev)   # noqa: E731
             kp3d = ops.h2d(np.asarray(scene["kp3d"], np.float32), dev)
+            geom_box = fo.box_geometry((H, W), bboxes, dev)
             out["kp_xy"] = fo.keypoints_to_frame(out["kp_idx"], geom_box, (R // 4, R // 4))   # :95-97 (64 x 64 heat-maps)
             out["_pose_raw"] = cpc_fit_device(f32(scene["focals"]), f32(scene["centers"]), out["kp_xy"], kp3d)   # :104-105
-            out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
-            if inp is not None:                                   # :133-143: the running composite starts from the frame
+            box = {}
+            if inp is not None:
                 rows = [[int(b[0]), int(b[1]), int(b[2]), int(b[3]), 0, 0, 0, 0] for b in np.asarray(inp["boxes"]).reshape(-1, 4)]
                 box = dict(box_images=out["inpaint_u8"], box_geom=ops.h2d(rows, dev, torch.int32))
-                back = frame
-            else:
-                box = {}
-                back = scene.get("background", frame)
-            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"], **box)       # :184-198
-            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"], **box)   # :236-250
-            out["geom"] = geom
+            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], out["geom"], scene["masks"], **box)       # :184-198
+            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], out["geom"], scene["masks"], **box)   # :236-250
         return out
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,

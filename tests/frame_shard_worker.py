@@ -1,0 +1,57 @@
+"""Worker of tests/test_bench_gpu.py::test_run_frame_sharded_over_two_ranks (not a test module): one rank of a gloo group on the
+box's card.  Every rank builds the same pipeline (synthetic weights of one seed) and the same scene; run_frame shards the
+frame's vehicles over the ranks; rank 0 compares the result with its own unsharded run_frame of the same scene (integers exact, images to the last place)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from future_urban_scene_generation_amd import ops
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    dev = torch.device("cuda:0")
+    ops.set_precision("f16x3")
+    inpaint = len(sys.argv) > 1 and sys.argv[1] == "inpaint"
+    pipe = VehiclePipeline(dev, inpaint=inpaint, seed=3)
+    ok = True
+    for V in (5, 1):                                                  # ragged shards (3 + 2), and an empty shard on rank 1
+        sc = synth_frame(V, (360, 640), dev, seed=20 + V, inpaint=inpaint)
+        sc["vehicle_seeds"] = [90 + v for v in range(V)]
+        got = pipe.run_frame(sc)
+        assert (got is None) == (rank != 0)
+        if rank == 0:
+            single = pipe.run_frame({**sc, "shard": False})
+            # the integer results are the same bits; the rendered crops may differ in the last place, because a network's
+            # launches (split-K factors, tile shapes) depend on the batch it is given and a shard is a smaller batch
+            for k in ("kp_idx", "kp_xy", "geom"):
+                if not torch.equal(got[k], single[k]):
+                    ok = False
+                    print("MISMATCH", V, k, flush=True)
+            for k, lim in (("vunet_u8", 1), ("icn_u8", 6), ("frame_icn", 6), ("frame_vunet", 2)) + ((("inpaint_u8", 1),) if inpaint else ()):
+                d = (got[k].to(torch.int32) - single[k].to(torch.int32)).abs()
+                frac = float((d > 0).float().mean())
+                print("diff", V, k, int(d.max()), "%.2e" % frac, flush=True)
+                if int(d.max()) > lim or frac > 2e-3:                  # (a Lab -> BGR conversion amplifies one Lab step)
+                    ok = False
+                    print("MISMATCH", V, k, int(d.max()), frac, flush=True)
+            for a, b in zip(got["pose"], single["pose"]):
+                for x, y in zip(a, b):
+                    if not np.allclose(np.asarray(x), np.asarray(y), rtol=1e-4, atol=1e-5, equal_nan=True):
+                        ok = False
+                        print("MISMATCH pose", V, flush=True)
+    frames = list(pipe.run_frames([sc]))                              # the generator form falls back to one sharded frame at a time
+    assert len(frames) == 1 and (frames[0] is None) == (rank != 0)
+    dist.barrier()
+    if rank == 0:
+        print("SHARD_OK" if ok else "SHARD_FAILED", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

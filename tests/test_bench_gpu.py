@@ -37,3 +37,25 @@ def test_bench_gpus2_self_spawn():
     line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "5 vehicles" in line["config"]["workload"]
     assert line["weights"].startswith("broadcast from rank 0")
+
+
+def test_run_frame_sharded_over_two_ranks():
+    """SURVEY 8(e) for the frame driver: `VehiclePipeline.run_frame` with a 2-rank process group (gloo, both ranks on
+    the box's card) - 5 vehicles as shards of 3 + 2, then 1 vehicle (rank 1's shard empty) - gives rank 0 what its own
+    unsharded call gives: keypoints and crop rows bit for bit, crops and composited frames to the last place (a shard is a
+    smaller batch: other split-K factors), poses alike (tests/frame_shard_worker.py)."""
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has initialised HIP: worker processes are started only from a process that has not")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "frame_shard_worker.py")], env={**base, "RANK": str(r)},
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert "SHARD_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
+    sys.stdout.write(outs[0][0])

@@ -144,3 +144,29 @@ def test_weight_broadcast_from_rank0():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+def test_slice_scene_partitions_the_vehicles():
+    """Host half of the sharded frame driver: the per-vehicle entries of a scene are cut at shard_range's bounds, the
+    frame-level ones are shared, and the shards put together are the scene again."""
+    import numpy as np
+    from future_urban_scene_generation_amd.pipeline import PER_VEHICLE_KEYS, slice_scene
+    V = 7
+    scene = {"frame": torch.zeros(4, 6, 3, dtype=torch.uint8), "focals": np.ones(2), "centers": np.ones(2),
+             "bboxes": np.arange(V * 4).reshape(V, 4), "masks": torch.arange(V).view(V, 1, 1).expand(V, 4, 6),
+             "src_sketch": torch.zeros(V, 4, 6, 3), "dst_sketch": torch.zeros(V, 4, 6, 3), "src_planes": torch.zeros(V, 5, 4, 6, 3),
+             "src_kp": [[v] for v in range(V)], "dst_kp": [[v] for v in range(V)], "src_vis": np.zeros((V, 5)), "dst_vis": np.zeros((V, 5)),
+             "kp3d": np.zeros((V, 12, 3)), "vehicle_seeds": list(range(V)),
+             "inpaint": {"boxes": np.arange(V * 4).reshape(V, 4), "img": torch.zeros(V, 3, 2, 2)}}
+    seen = []
+    for r in range(3):
+        lo, hi = shard_range(V, r, 3)
+        sub = slice_scene(scene, lo, hi)
+        assert sub["frame"] is scene["frame"] and sub["focals"] is scene["focals"]
+        for k in PER_VEHICLE_KEYS:
+            assert len(sub[k]) == hi - lo, k
+        assert len(sub["inpaint"]["boxes"]) == hi - lo and sub["inpaint"]["img"].shape[0] == hi - lo
+        seen += list(sub["vehicle_seeds"])
+        assert sub["src_kp"] == [[v] for v in range(lo, hi)] and sub["masks"][:, 0, 0].tolist() == list(range(lo, hi))
+    assert seen == list(range(V))
+    assert len(scene["bboxes"]) == V                                           # the caller's dict is untouched
