@@ -22,6 +22,7 @@ _DT = {torch.float32: L.F32, torch.uint8: L.U8, torch.int32: L.I32}
 # "f16x3" = split-fp16 (fp32-class accuracy, 3 passes at the fp16 matrix rate).  Process-wide default,
 # overridable per call; FUSG_PRECISION in the environment sets the initial value.
 import os as _os
+import numpy as _np
 
 
 def _env_set(name: str) -> bool:
@@ -263,6 +264,8 @@ def h2d(a, device, dtype=None) -> torch.Tensor:
     pinned memory (torch's caching host allocator holds the block until the copy has run) and copied asynchronously.
     `torch.tensor(..., device=...)` / `.to(device)` from pageable memory wait for everything queued on the stream - one
     such call per frame is enough to serialise `VehiclePipeline.run_frames`' host against its GPU."""
+    if isinstance(a, _np.ndarray) and not a.flags.writeable:
+        a = a.copy()                       # (a broadcast view: torch refuses to wrap read-only memory silently)
     t = a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)

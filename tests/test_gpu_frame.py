@@ -298,3 +298,22 @@ def test_run_frame_with_inpainting_matches_the_oracle():
     for k in ("kp_idx", "icn_u8", "vunet_u8", "inpaint_u8", "frame_icn", "frame_vunet"):
         assert torch.equal(rep[k], got[k]), k
         assert torch.equal(seq[0][k], got[k]) and torch.equal(seq[1][k], got[k]), k
+
+
+@pytest.mark.gpu
+def test_run_frame_without_vehicles():
+    """A frame the detector found nothing in (the reference's loop body never runs): empty per-vehicle results, both
+    composited frames equal to the input frame - through run_frame and run_frames."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    pipe = VehiclePipeline(DEV)
+    full = synth_frame(1, (180, 320), DEV, seed=2)
+    H, W = 180, 320
+    e = lambda *sh: torch.empty(sh, dtype=torch.uint8, device=DEV)           # noqa: E731
+    sc = {"frame": full["frame"], "bboxes": np.zeros((0, 4), np.int64), "masks": e(0, H, W), "src_sketch": e(0, H, W, 3),
+          "dst_sketch": e(0, H, W, 3), "src_planes": e(0, 5, H, W, 3), "src_kp": [], "dst_kp": [], "src_vis": np.zeros((0, 5), np.uint8),
+          "dst_vis": np.zeros((0, 5), np.uint8), "kp3d": np.zeros((0, 12, 3), np.float32), "focals": full["focals"], "centers": full["centers"]}
+    outs = [pipe.run_frame(sc), pipe.run_frame(sc, replay=True)] + list(pipe.run_frames([sc, full, sc]))
+    for o in (outs[0], outs[1], outs[2], outs[4]):
+        assert o["pose"] == [] and o["kp_idx"].shape == (0, 12) and o["icn_u8"].shape == (0, 256, 256, 3)
+        assert torch.equal(o["frame_icn"], sc["frame"]) and torch.equal(o["frame_vunet"], sc["frame"])
+    assert outs[3]["kp_idx"].shape == (1, 12) and not torch.equal(outs[3]["frame_vunet"], full["frame"])
