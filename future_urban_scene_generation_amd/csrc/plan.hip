@@ -8,10 +8,9 @@
 // dependencies (record an event on one stream, wait for it on another) and host-to-device copies of per-pass data
 // (the VUnet's CPU-drawn noise, from a ring of pinned buffers).  fusg_plan_run then re-issues the sequence in order on the recorded streams.
 //
-// This is deliberately not a hipGraph: on ROCm 7.2 a captured multi-stream pass replays 40-60 % SLOWER than eager
-// launching (measured in round 1, DESIGN.md §7: graph nodes are dispatched through one queue with a barrier per node,
-// so the small launches of the three branches no longer overlap).  A plan keeps eager semantics - same streams, same
-// priorities, same overlap - and only removes the interpreter from the issue path.
+// This is deliberately not a hipGraph: on ROCm 7.2 a captured multi-stream pass replayed 40-60 % SLOWER than eager
+// launching when it was measured in round 1 (cause never established with a trace: DESIGN.md §9).  A plan keeps eager
+// semantics - same streams, same priorities, same overlap - and only removes the interpreter from the issue path.
 //
 // Contract: every device pointer a recorded call used must stay valid and keep its meaning until the plan is destroyed
 // (the Python side records inside a private torch memory pool and keeps the pool), inputs are refreshed in place.
