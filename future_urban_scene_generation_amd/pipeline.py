@@ -452,7 +452,8 @@ class VehiclePipeline:
             # for the next frame (whose launches queue behind these copies), one event to wait on
             ring = self.__dict__.setdefault("_frame_pins", [])
             raw = out.pop("_pose_raw")
-            pins = ring.pop() if ring and all(a.shape == b.shape for a, b in zip(ring[-1][0], raw)) else \
+            hit = [i for i, pr in enumerate(ring) if all(a.shape == b.shape for a, b in zip(pr[0], raw))]
+            pins = ring.pop(hit[0]) if hit else \
                 ([torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in raw], torch.zeros(1, dtype=torch.int32, pin_memory=True))
             for h, t in zip(pins[0], raw):
                 h.copy_(t, non_blocking=True)
