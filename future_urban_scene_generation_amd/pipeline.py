@@ -113,6 +113,8 @@ def load_schema(net: str):
     return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
 
 
+FRAME_PLANS = int(os.environ.get("FUSG_FRAME_PLANS", "6"))     # recorded passes kept by run_frame(replay=True), one per vehicle count
+
 PER_VEHICLE_KEYS = ("bboxes", "masks", "src_sketch", "dst_sketch", "src_planes", "src_kp", "dst_kp", "src_vis", "dst_vis", "kp3d",
                     "vehicle_seeds")
 
@@ -540,7 +542,14 @@ class VehiclePipeline:
                 nets_in.update(ec_img=inp["img"], ec_gray=inp["gray"], ec_edge=inp["edge"], ec_mask=inp["mask"])
             if replay:
                 if cp is None:
+                    # one recorded pass (with its private pool of intermediates) per vehicle count; a video whose count varies
+                    # keeps the FRAME_PLANS most recently used ones
+                    cps.pop((V, ops.PRECISION), None)
+                    while len(cps) >= FRAME_PLANS:
+                        cps.pop(next(iter(cps)))
                     cp = cps[(V, ops.PRECISION)] = CompiledPass(self, nets_in, seeds)
+                else:
+                    cps[(V, ops.PRECISION)] = cps.pop((V, ops.PRECISION))     # most recently used last
                 out = dict(cp._issue(nets_in, seeds))
                 for k in ("vunet_u8", "kp_idx", "inpaint_u8"):    # the plan's buffers belong to its next replay
                     if k in out:

@@ -317,3 +317,24 @@ def test_run_frame_without_vehicles():
         assert o["pose"] == [] and o["kp_idx"].shape == (0, 12) and o["icn_u8"].shape == (0, 256, 256, 3)
         assert torch.equal(o["frame_icn"], sc["frame"]) and torch.equal(o["frame_vunet"], sc["frame"])
     assert outs[3]["kp_idx"].shape == (1, 12) and not torch.equal(outs[3]["frame_vunet"], full["frame"])
+
+
+@pytest.mark.gpu
+def test_frame_plans_are_bounded(monkeypatch):
+    """A video whose vehicle count varies: run_frame(replay=True) keeps one recorded pass per count, at most FRAME_PLANS of
+    them (least recently used out), and a frame whose pass was evicted while it was still in flight comes back intact."""
+    from future_urban_scene_generation_amd import pipeline as P
+    monkeypatch.setattr(P, "FRAME_PLANS", 2)
+    pipe = P.VehiclePipeline(DEV)
+    scenes = {}
+    for V in (1, 2, 3):
+        sc = P.synth_frame(V, (180, 320), DEV, seed=30 + V)
+        sc["vehicle_seeds"] = list(range(V))
+        scenes[V] = sc
+    want = {V: pipe.run_frame(sc) for V, sc in scenes.items()}
+    order = [1, 2, 3, 1, 3, 2]
+    got = list(pipe.run_frames([scenes[V] for V in order]))
+    assert len(pipe._frame_plans) <= 2
+    for g, V in zip(got, order):
+        for k in ("kp_idx", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
+            assert torch.equal(g[k], want[V][k]), (V, k)
