@@ -135,11 +135,14 @@ class VehiclePipeline:
     """Holds the five networks on one device and runs batches of crops through them."""
 
     def __init__(self, device, inpaint: bool = False, state_dicts: Optional[Dict[str, dict]] = None, seed: int = 0,
-                 broadcast_src: Optional[int] = None, group=None):
+                 broadcast_src: Optional[int] = None, group=None, cad: bool = False):
         """state_dicts: checkpoints (the reference's keys) per network; a missing network gets the synthetic weights of
         `seed`.  broadcast_src: with an initialised process group, only that rank needs to hold `state_dicts` (a real
         checkpoint read from disk on rank 0): they are distributed with `broadcast_state_dicts` first (north_star: RCCL
-        broadcast of the shared weights), so every rank renders with identical parameters."""
+        broadcast of the shared weights), so every rank renders with identical parameters.
+        cad: also hold the reference's CAD-model classifier (VGG-19, 10 classes; state_dicts['vgg'] = `cads/model.pth`,
+        run_test.py:47-58) and run it on the hourglass's crop in every pass (trajectory_inference.py:66-69): 'cad_logits' /
+        `run_frame`'s 'cad_idx'.  Not part of BASELINE's crop pass: `bench.py` leaves it off."""
         from .edgeconnect.models import EdgeModel, InpaintingModel
         from .stacked_hourglass.models import HourglassNet
         from .synth import synth_state_dict
@@ -148,6 +151,7 @@ class VehiclePipeline:
         self.device = torch.device(device)
         self.inpaint = inpaint
         self.group = group
+        self.cad = None
         if broadcast_src is not None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -173,6 +177,12 @@ class VehiclePipeline:
             self.edge.generator.load_state_dict(sd("edge"))
             self.inp.generator.load_state_dict(sd("inpaint"))
             nets += [self.edge, self.inp]
+        if cad:
+            from .cad_classifier import VGG19Classifier, vgg19_schema
+            self.cad = VGG19Classifier(10)
+            self.cad.load_state_dict(state_dicts["vgg"] if state_dicts is not None and "vgg" in state_dicts
+                                     else synth_state_dict("vgg", vgg19_schema(10), seed))
+            nets.append(self.cad)
         for n in nets:
             n.to(self.device).eval()
         # the FusedNets whose packed-weight caches a recorded pass points into (EdgeModel / InpaintingModel wrap theirs)
@@ -328,11 +338,16 @@ class VehiclePipeline:
                    "vunet_u8": torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)}
             if self.inpaint:
                 out["inpaint_u8"] = torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)
+            if self.cad is not None:
+                out["cad_logits"] = torch.empty((0, 10), dtype=torch.float32, device=dev)
             return out
         self.vunet.set_vehicle_seeds(vehicle_seeds)
 
         def hg():
-            return {"kp_idx": ops.argmax_hw(self.hg(batch["hg_x"])["heatmaps"][-1])}
+            out = {"kp_idx": ops.argmax_hw(self.hg(batch["hg_x"])["heatmaps"][-1])}
+            if self.cad is not None:                              # same crop, same branch (:66-69): a stream of its own costs more
+                out["cad_logits"] = self.cad(batch["hg_x"])
+            return out
 
         def icn():
             return {"icn_u8": ops.to_image_u8(self.icn(batch["icn_x"]))}
@@ -384,6 +399,8 @@ class VehiclePipeline:
         this many vehicles and kept per vehicle count) instead of ~370 launches from Python: at 8 vehicles per frame the
         interpreter, not the GPU, bounds the eager form.
 
+        A pipeline built with cad=True classifies every vehicle's box crop (VGG-19, :66-69) and returns 'cad_idx' int64 [V]; with
+        'kp3d_bank' float32 [n_cad, 12, 3] in the scene the pose fit uses the chosen model's keypoints (:82-88) instead of 'kp3d'.
         With an initialised process group of more than one rank the frame's vehicles are sharded over the ranks (every rank
         passes the same scene; rank 0 returns the result, the others None; scene['shard'] = False keeps a rank on its own).
 
@@ -403,7 +420,7 @@ class VehiclePipeline:
             lo, hi = shard_range(V, rank, world)
             local = self._guarded(self._frame_local, (slice_scene(scene, lo, hi), replay), check, rng)
             full = {}
-            for k in ("kp_idx", "icn_u8", "vunet_u8", "geom") + (("inpaint_u8",) if self.inpaint else ()):
+            for k in ("kp_idx", "icn_u8", "vunet_u8", "geom") + (("inpaint_u8",) if self.inpaint else ()) + (("cad_idx",) if self.cad is not None else ()):
                 g = gather_in_order(local[k].contiguous(), V, self.group)
                 full[k] = None if g is None else g.to(self.device)
             if rank != 0:
@@ -517,6 +534,8 @@ class VehiclePipeline:
                        "geom": torch.empty((0, 8), dtype=torch.int32, device=dev)}
                 if inp is not None:
                     out["inpaint_u8"] = e8()
+                if self.cad is not None:
+                    out["cad_idx"] = torch.empty((0,), dtype=torch.int64, device=dev)
                 return out
             replay = replay and ops.RECORDER is None
             cps = self.__dict__.setdefault("_frame_plans", {})
@@ -551,13 +570,15 @@ class VehiclePipeline:
                 else:
                     cps[(V, ops.PRECISION)] = cps.pop((V, ops.PRECISION))     # most recently used last
                 out = dict(cp._issue(nets_in, seeds))
-                for k in ("vunet_u8", "kp_idx", "inpaint_u8"):    # the plan's buffers belong to its next replay
+                for k in ("vunet_u8", "kp_idx", "inpaint_u8", "cad_logits"):    # the plan's buffers belong to its next replay
                     if k in out:
                         out[k] = out[k].clone()
             else:
                 out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
             out["geom"] = geom
+            if "cad_logits" in out:
+                out["cad_idx"] = out.pop("cad_logits").argmax(1)                               # :69
         return out
 
     @torch.no_grad()
@@ -585,7 +606,10 @@ class VehiclePipeline:
                 out["frame_icn"], out["frame_vunet"] = back.clone(), back.clone()
                 return out
             f32 = lambda a: ops.h2d(np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32).reshape(-1, 2), (V, 2))), dev)   # noqa: E731
-            kp3d = ops.h2d(np.asarray(scene["kp3d"], np.float32), dev)
+            if self.cad is not None and scene.get("kp3d_bank") is not None:                    # :82-88: the chosen CAD model's keypoints
+                kp3d = ops.h2d(np.asarray(scene["kp3d_bank"], np.float32), dev)[out["cad_idx"]]
+            else:
+                kp3d = ops.h2d(np.asarray(scene["kp3d"], np.float32), dev)
             geom_box = fo.box_geometry((H, W), bboxes, dev)
             out["kp_xy"] = fo.keypoints_to_frame(out["kp_idx"], geom_box, (R // 4, R // 4))   # :95-97 (64 x 64 heat-maps)
             out["_pose_raw"] = cpc_fit_device(f32(scene["focals"]), f32(scene["centers"]), out["kp_xy"], kp3d)   # :104-105

@@ -20,6 +20,7 @@ from .host import to_image_u8, to_tensor_pm1
 from .edgeconnect import edge_model_forward, inpaint_model_forward
 from .hourglass import get_maxima, heatmap_argmax, hourglass_forward
 from .icn import icn_forward
+from .vgg import vgg19_forward
 from .vunet import vunet_forward
 
 MEAN = np.array([0.485, 0.456, 0.406], np.float32)          # trajectory_inference.py:62-64
@@ -64,7 +65,13 @@ def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dic
         kp[:, 0] = kp[:, 0] * (x1 - x0) + x0 - pb[0]                                          # :95-97
         kp[:, 1] = kp[:, 1] * (y1 - y0) + y0 - pb[1]
         kp32 = kp.astype(np.float32)
-        pose = pnp.cpc_rodr_4_angles(scene["focals"], scene["centers"], kp32, scene["kp3d"][v])[:3]   # :104-105
+        kp3d = scene["kp3d"][v]
+        if "vgg" in state_dicts:                                                              # :66-69 (VGG-19: unpinned, oracle/vgg.py)
+            cad = int(vgg19_forward(state_dicts["vgg"], x)[0].numpy().argmax())
+            res_.setdefault("cad_idx", []).append(np.int64(cad))
+            if scene.get("kp3d_bank") is not None:
+                kp3d = np.asarray(scene["kp3d_bank"], np.float32)[cad]                        # :82-88
+        pose = pnp.cpc_rodr_4_angles(scene["focals"], scene["centers"], kp32, kp3d)[:3]       # :104-105
         if inp is not None:                                                                   # :121-143, inputs given (see run_frame)
             t = lambda k: torch.from_numpy(np.ascontiguousarray(inp[k][v:v + 1]))              # noqa: E731
             e = edge_model_forward(state_dicts["edge"], t("gray"), t("edge"), t("mask"))       # :124

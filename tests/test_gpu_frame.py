@@ -338,3 +338,39 @@ def test_frame_plans_are_bounded(monkeypatch):
     for g, V in zip(got, order):
         for k in ("kp_idx", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
             assert torch.equal(g[k], want[V][k]), (V, k)
+
+
+@pytest.mark.gpu
+def test_run_frame_with_the_cad_classifier():
+    """§8f-4 in the chain: a pipeline built with cad=True classifies every vehicle's box crop (VGG-19, 10 classes) on the
+    hourglass's branch, returns the CAD index and fits the pose against the chosen model's keypoints ('kp3d_bank').  Against
+    oracle.frame_pass: CAD indices and keypoints exact, the other outputs as without the classifier; replay == eager."""
+    from future_urban_scene_generation_amd.cad_classifier import vgg19_schema
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    from future_urban_scene_generation_amd.synth import synth_state_dict
+    from future_urban_scene_generation_amd import ops
+    ops.set_precision("f16x3")
+    V = 2
+    sds = {n: synth_sd(n) for n in ("hg", "icn", "vunet")}
+    sds["vgg"] = synth_state_dict("vgg", vgg19_schema(10), 0)
+    pipe = VehiclePipeline(DEV, state_dicts=sds, cad=True)
+    sc = synth_frame(V, (360, 640), DEV, seed=23)
+    sc["vehicle_seeds"] = [7, 8]
+    g = np.random.default_rng(4)
+    sc["kp3d_bank"] = (g.uniform(-1, 1, (10, 12, 3)) * np.array([0.9, 0.5, 2.0]) * 5).astype(np.float32)
+    got = pipe.run_frame(sc)
+    ref = oracle.frame_pass(sds, _scene_cpu(sc))
+    assert got["cad_idx"].cpu().numpy().tolist() == [int(c) for c in ref["cad_idx"]]
+    assert np.array_equal(got["kp_idx"].cpu().numpy(), ref["kp_idx"]) and np.array_equal(got["kp_xy"].cpu().numpy(), ref["kp_xy"])
+    assert int(np.abs(got["vunet_u8"].cpu().numpy().astype(int) - ref["vunet_u8"].astype(int)).max()) <= 1
+    from oracle import pnp as opnp
+    for v in range(V):
+        (e, rv, tv), (oe, orv, otv) = got["pose"][v], ref["pose"][v]
+        if np.isfinite(e) and np.isfinite(oe) and float(oe) > 0 and abs(float(e) / float(oe) - 1) < 1e-3:
+            assert np.abs(opnp.rodrigues(rv) - opnp.rodrigues(orv)).max() < 1e-3
+    rep = pipe.run_frame(sc, replay=True)
+    seq = list(pipe.run_frames([sc, sc]))
+    for k in ("cad_idx", "kp_idx", "icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
+        assert torch.equal(rep[k], got[k]) and torch.equal(seq[1][k], got[k]), k
+    for a, b in zip(seq[0]["pose"], got["pose"]):
+        assert all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(a, b))

@@ -16,7 +16,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 INP = len(sys.argv) > 3 and sys.argv[3] == "inpaint"
-pipe = VehiclePipeline(dev, inpaint=INP)
+CAD = len(sys.argv) > 3 and sys.argv[3] == "cad"            # + the VGG-19 CAD classifier on the hourglass's branch
+pipe = VehiclePipeline(dev, inpaint=INP, cad=CAD)
 scenes = []
 for sd in (3, 4):
     sc = synth_frame(V, (720, 1280), dev, seed=sd, inpaint=INP)
