@@ -361,7 +361,8 @@ class VehiclePipeline:
             mu_app, _ = vu.forward_enc_down(eo, es)
             join()
             xt, _, _ = vu.forward_dec_down(do, ds, mu_app)
-            return {"vunet_u8": ops.to_image_u8(xt)}
+            # (the appearance code is what a vehicle's FUTURE frames are rendered with, :424-426: run_frame hands it out)
+            return {"vunet_u8": ops.to_image_u8(xt), "mu_app_0": mu_app[0], "mu_app_1": mu_app[1]}
 
         def inpaint():
             e = self.edge(batch["ec_gray"], batch["ec_edge"], batch["ec_mask"])      # :124-129
@@ -405,7 +406,8 @@ class VehiclePipeline:
         passes the same scene; rank 0 returns the result, the others None; scene['shard'] = False keeps a rank on its own).
 
         Returns 'kp_idx' int32 [V, 12], 'kp_xy' float32 [V, 12, 2], 'pose' = list of (error, rvec [3, 1], tvec [3, 1]),
-        'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8]."""
+        'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8],
+        'state' = what `run_later_frame` needs to render the same vehicles' future frames (VUnet appearance code, central crop)."""
         rng = torch.get_rng_state() if check == "sync" else None
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -425,7 +427,7 @@ class VehiclePipeline:
                 full[k] = None if g is None else g.to(self.device)
             if rank != 0:
                 return None
-            out = self._frame_finish(scene, full)
+            out = self._frame_finish(scene, full)                 # (no 'state': the appearance codes stay on the ranks that made them)
         else:
             out = self._guarded(self._run_frame, (scene, replay), check, rng)
         # the reference's host epilogue of the pose fit (argmin over the four starts, sign flip): 4 x 7 numbers per vehicle
@@ -570,13 +572,14 @@ class VehiclePipeline:
                 else:
                     cps[(V, ops.PRECISION)] = cps.pop((V, ops.PRECISION))     # most recently used last
                 out = dict(cp._issue(nets_in, seeds))
-                for k in ("vunet_u8", "kp_idx", "inpaint_u8", "cad_logits"):    # the plan's buffers belong to its next replay
+                for k in ("vunet_u8", "kp_idx", "inpaint_u8", "cad_logits", "mu_app_0", "mu_app_1"):    # the plan's buffers belong to its next replay
                     if k in out:
                         out[k] = out[k].clone()
             else:
                 out = self._run(nets_in, seeds)                                                # :75-79, :182, :230-234
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])                                          # to_image(from_LAB=True), :182
             out["geom"] = geom
+            out["central"] = central
             if "cad_logits" in out:
                 out["cad_idx"] = out.pop("cad_logits").argmax(1)                               # :69
         return out
@@ -619,6 +622,63 @@ class VehiclePipeline:
                 box = dict(box_images=out["inpaint_u8"], box_geom=ops.h2d(rows, dev, torch.int32))
             out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], out["geom"], scene["masks"], **box)       # :184-198
             out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], out["geom"], scene["masks"], **box)   # :236-250
+            if "mu_app_0" in out:                                 # what `run_later_frame` renders these vehicles' future frames with
+                out["state"] = {"appearance": [out.pop("mu_app_0"), out.pop("mu_app_1")], "central": out.pop("central")}
+        return out
+
+    # ------------------------------------------------------------------------------------------ future frames of a clip
+    def run_later_frame(self, scene: Dict, state: Dict, check: Optional[str] = "sync") -> Dict:
+        """A FUTURE frame of vehicles whose first frame `run_frame` rendered (trajectory_inference.py:283-450, per vehicle and
+        trajectory step): no hourglass, no pose fit, no appearance encoder - the source planes warped to the new pose -> ICN
+        inputs (with the first frame's central crop) -> ICN -> Lab image (:376-391); the new sketch -> VUnet shape encoder ->
+        decoder conditioned on the FIRST frame's appearance code (:415-426); ordered paste of both (:393-410, :428-445).
+
+        scene: as for `run_frame`, but rendered for the new pose - 'frame' (what is pasted onto; 'background' overrides),
+        'masks', 'dst_sketch', 'dst_kp', 'dst_vis' of the new pose, 'src_planes' / 'src_kp' / 'src_vis' of the first frame,
+        optional 'vehicle_seeds' (the shape decoder draws its sampler noise: a seed per vehicle and frame keeps a vehicle's
+        images independent of batching); state: `run_frame(...)["state"]` of the same vehicles, same order.
+        Returns 'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom'."""
+        rng = torch.get_rng_state() if (check == "sync" and scene.get("vehicle_seeds") is None) else None
+        return self._guarded(self._run_later_frame, (scene, state), check, rng)
+
+    @torch.no_grad()
+    def _run_later_frame(self, scene, state):
+        from . import frame_ops as fo
+        from . import ops
+        from .warp_learn import planes_utils as pu
+        dev = self.device
+        frame = scene["frame"]
+        R = 256
+        V = int(scene["masks"].shape[0])
+        if state["central"].shape[0] != V:
+            raise ValueError(f"run_later_frame: the state holds {state['central'].shape[0]} vehicles, the scene {V}")
+        with torch.cuda.device(dev):
+            back = scene.get("background", frame)
+            if V == 0:
+                e8 = torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)
+                return {"icn_u8": e8, "vunet_u8": e8.clone(), "frame_icn": back.clone(), "frame_vunet": back.clone(),
+                        "geom": torch.empty((0, 8), dtype=torch.int32, device=dev)}
+            jobs = pu.warp_jobs_frame(scene["src_kp"], scene["dst_kp"], scene["src_vis"], scene["dst_vis"])
+            warped = pu.warp_planes_batch(scene["src_planes"], jobs)                           # :376-381
+            _, geom = fo.mask_bbox_geom(scene["masks"])
+            icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], state["central"], geom, R, R)   # :385-387
+            _, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["dst_sketch"], scene["dst_sketch"], geom, R)   # :415-420 (y_tilde only)
+            self.vunet.set_vehicle_seeds(scene.get("vehicle_seeds"))
+
+            def icn():
+                return {"icn_u8": ops.to_image_u8(self.icn(icn_x))}                            # :389
+
+            def vunet():
+                vu = self.vunet
+                do, ds = vu.forward_dec_up(vu_y)                                               # :424
+                xt, _, _ = vu.forward_dec_down(do, ds, list(state["appearance"]))              # :425
+                return {"vunet_u8": ops.to_image_u8(xt)}                                       # :426
+
+            out = self._branches([("icn", icn), ("vunet", vunet)])
+            out["icn_u8"] = pu.lab2bgr(out["icn_u8"])
+            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"])       # :393-410
+            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"])   # :428-445
+            out["geom"] = geom
         return out
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,

@@ -132,7 +132,9 @@ def find_homography_batch(pairs: Sequence[Tuple[np.ndarray, np.ndarray]]) -> Lis
     """`find_homography` for many point sets at once - the same arithmetic per problem (normalised DLT through the symmetric
     eigen-decomposition, then Levenberg-Marquardt with the same acceptance rule), vectorised over the problems of equal point
     count: a frame of 8 vehicles needs ~46 fits, and one Python call per fit (150 us of numpy overhead each) was the largest
-    host cost of `VehiclePipeline.run_frame`.  Returns one 3x3 matrix (or None) per pair, in order."""
+    host cost of `VehiclePipeline.run_frame`.  Returns one 3x3 matrix (or None) per pair, in order.  The matrices equal
+    `find_homography`'s bit for bit on well-posed fits (tests/test_cv_host_cpu.py); on a near-degenerate one (condition number
+    ~1e9: unrelated quadrilaterals) LAPACK's batched and single eigen-decompositions differ in the last place."""
     out: List[Optional[np.ndarray]] = [None] * len(pairs)
     groups: Dict[int, List[int]] = {}
     for i, (sp, dp) in enumerate(pairs):

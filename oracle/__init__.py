@@ -34,7 +34,7 @@ from .edgeconnect import (edge_generator_forward, inpaint_generator_forward,  # 
                           edge_model_forward, inpaint_model_forward)
 from .host import to_image_u8, to_tensor_pm1, ssim                            # noqa: F401
 from .pipeline import crop_pass                                               # noqa: F401
-from .frame import frame_pass                                                 # noqa: F401
+from .frame import frame_pass, later_frame_pass                               # noqa: F401
 from . import cv_host                                                         # noqa: F401
 from . import pnp                                                             # noqa: F401
 from .vgg import vgg19_forward                                                # noqa: F401

@@ -21,7 +21,7 @@ from .edgeconnect import edge_model_forward, inpaint_model_forward
 from .hourglass import get_maxima, heatmap_argmax, hourglass_forward
 from .icn import icn_forward
 from .vgg import vgg19_forward
-from .vunet import vunet_forward
+from .vunet import vunet_dec_down, vunet_dec_up, vunet_forward
 
 MEAN = np.array([0.485, 0.456, 0.406], np.float32)          # trajectory_inference.py:62-64
 STD = np.array([0.229, 0.224, 0.225], np.float32)
@@ -95,7 +95,8 @@ def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dic
         vx, vy = vunet_inputs(frame, scene["masks"][v], scene["src_sketch"][v], scene["dst_sketch"][v], res)
         if seeds is not None:
             torch.manual_seed(int(seeds[v]))
-        xt = vunet_forward(state_dicts["vunet"], vy, vx, first_frame_like_traj_test=True)[0]  # :230-233
+        xt, mu_app, _ = vunet_forward(state_dicts["vunet"], vy, vx, first_frame_like_traj_test=True)   # :230-233
+        res_.setdefault("state", []).append({"appearance": mu_app, "central": central})
         vimg = to_image_u8(xt[0])                                                             # :234
         cv.paste_back(out_vu, vimg, info, mask)                                               # [cv] :236-250
         for k, val in (("kp_idx", heatmap_argmax(hm)[0].astype(np.int32)), ("kp_xy", kp32), ("pose", pose), ("icn_u8", net),
@@ -104,6 +105,39 @@ def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dic
                        ("geom", [info["crop_xy_min"][0], info["crop_xy_min"][1], info["crop_xy_min"][0] + info["crop_size_orig"][1],
                                  info["crop_xy_min"][1] + info["crop_size_orig"][0], *info["pad_xy_before"], *info["pad_xy_after"]])):
             res_[k].append(val)
-    out = {k: (np.stack(v) if k != "pose" else v) for k, v in res_.items()}
+    out = {k: (np.stack(v) if k not in ("pose", "state") else v) for k, v in res_.items()}
+    out["frame_icn"], out["frame_vunet"] = out_icn, out_vu
+    return out
+
+
+def later_frame_pass(state_dicts: Dict[str, dict], scene: Dict, state, res: int = 256) -> Dict:
+    """A future frame of the same vehicles (trajectory_inference.py:283-450, one trajectory step), vehicle by vehicle: the
+    counterpart of VehiclePipeline.run_later_frame.  state = frame_pass(...)["state"] (per vehicle: the VUnet appearance
+    code of the first frame and its central crop)."""
+    frame = scene["frame"]
+    back = scene.get("background", frame)
+    out_icn, out_vu = back.copy(), back.copy()
+    V = len(scene["masks"])
+    res_ = {k: [] for k in ("icn_u8", "vunet_u8", "geom")}
+    seeds = scene.get("vehicle_seeds")
+    for v in range(V):
+        warped, _ = cv.warp_unwarp_planes(scene["src_planes"][v], scene["src_kp"][v], scene["dst_kp"][v],
+                                          scene["src_vis"][v], scene["dst_vis"][v])           # [cv] :376-381
+        mask = scene["masks"][v].astype(bool)
+        icn_x, info = cv.get_icn_inputs(warped, scene["dst_sketch"][v], mask, state[v]["central"], res, res)   # [cv] :385-387
+        net = cv.lab2bgr_u8(to_image_u8(icn_forward(state_dicts["icn"], torch.from_numpy(np.ascontiguousarray(icn_x)))[0]))   # :389
+        cv.paste_back(out_icn, net, info, mask)                                               # [cv] :393-410
+        _, vy = vunet_inputs(frame, scene["masks"][v], scene["dst_sketch"][v], scene["dst_sketch"][v], res)   # :415-420
+        if seeds is not None:
+            torch.manual_seed(int(seeds[v]))
+        outs, skips = vunet_dec_up(state_dicts["vunet"], vy)                                  # :424
+        xt = vunet_dec_down(state_dicts["vunet"], outs, skips, state[v]["appearance"])[0]     # :425
+        vimg = to_image_u8(xt[0])                                                             # :426
+        cv.paste_back(out_vu, vimg, info, mask)                                               # [cv] :428-445
+        res_["icn_u8"].append(net)
+        res_["vunet_u8"].append(vimg)
+        res_["geom"].append([info["crop_xy_min"][0], info["crop_xy_min"][1], info["crop_xy_min"][0] + info["crop_size_orig"][1],
+                             info["crop_xy_min"][1] + info["crop_size_orig"][0], *info["pad_xy_before"], *info["pad_xy_after"]])
+    out = {k: np.stack(v) for k, v in res_.items()}
     out["frame_icn"], out["frame_vunet"] = out_icn, out_vu
     return out
