@@ -22,6 +22,16 @@ from oracle import cv_host as C                                            # noq
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _oracle_threads():
+    """The CPU oracle runs one vehicle at a time: with every core of a 256-CPU box in torch's pool a batch-1 convolution
+    is slower than with 16 threads (bench.py's sweep)."""
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, len(os.sched_getaffinity(0)))))
+    yield
+    torch.set_num_threads(nt)
+
+
 def _scene_cpu(scene):
     out = {}
     for k, v in scene.items():
