@@ -59,3 +59,25 @@ def test_reference_signature_and_batch_of_64_vehicles():
     z = np.zeros((1, 12, 3), np.float32)
     res = prod.cpc_rodr_4_angles_batch(probs[0][0], probs[0][1], probs[0][2][None], z)
     assert len(res) == 1
+
+
+@pytest.mark.parametrize("n", [8, 5, 16])
+def test_other_point_counts_take_the_generic_kernel(n):
+    """12 keypoints run the unrolled instantiation; any other count (fewer visible keypoints, up to 16) runs the generic one -
+    the same arithmetic: against the oracle on the first n points of a problem (n = 5: fewer points than the six the
+    Jacobian uses, cpc.py:30)."""
+    for case in (3, 4):
+        f, c, p2, p3 = opnp.pnp_problem(case)
+        if n > 12:
+            g = np.random.default_rng(case)
+            p3 = np.concatenate([p3, p3[:n - 12] + g.normal(0, 0.1, (n - 12, 3)).astype(np.float32)])
+            p2 = np.concatenate([p2, p2[:n - 12] + g.normal(0, 2.0, (n - 12, 2)).astype(np.float32)])
+        p2, p3 = p2[:n], p3[:n]
+        e, r, t = prod.cpc_rodr_4_angles(f, c, p2, p3)
+        oe, orv, otv = opnp.cpc_rodr_4_angles(f, c, p2, p3)[:3]
+        if not (np.isfinite(oe) and np.isfinite(e)):
+            assert np.isfinite(oe) == np.isfinite(e)
+            continue
+        assert abs(e / oe - 1) < 1e-3, (n, case, e, oe)
+        if abs(e / oe - 1) < 2e-4:                                                  # same minimum reached: same pose
+            assert np.abs(opnp.rodrigues(r) - opnp.rodrigues(orv)).max() < 1e-4
