@@ -20,30 +20,37 @@ _ALIASES = {
     "vunet.layers": "future_urban_scene_generation_amd.vunet.layers",
     "edgeconnect.networks": "future_urban_scene_generation_amd.edgeconnect.networks",
     "edgeconnect.models": "future_urban_scene_generation_amd.edgeconnect.models",
-    # pose fit (cpc_rodr_4_angles): only this sub-module of the reference's `utils` package is replaced
-    "utils.pnp_utils": "future_urban_scene_generation_amd.utils.pnp_utils",
 }
 
 
-# opt-in only: the uint8 image steps (to_image, warp_unwarp_planes, get_planes, planes_to_torch) restate OpenCV's
-# arithmetic and their parity with a particular OpenCV build is unpinned (oracle/cv_host.py)
-_OPT_IN_ALIASES = {"warp_learn.planes_utils": "future_urban_scene_generation_amd.warp_learn.planes_utils"}
+# Opt-in only - ONE policy for every module that restates third-party (OpenCV) arithmetic whose parity with the build the
+# reference runs on is unpinned (oracle/cv_host.py, oracle/pnp.py):
+#   planes_utils: the uint8 image steps (to_image, warp_unwarp_planes, get_planes, planes_to_torch);
+#   pnp:          the pose fit (cpc_rodr_4_angles).  north_star keeps PnP host-side; the device fit itself is pinned to the
+#                 reference's CPC_R, its cv2.Rodrigues epilogue is not.
+_OPT_IN_ALIASES = {"planes_utils": {"warp_learn.planes_utils": "future_urban_scene_generation_amd.warp_learn.planes_utils"},
+                   "pnp": {"utils.pnp_utils": "future_urban_scene_generation_amd.utils.pnp_utils"}}
 
 
-def install(names=None, planes_utils=None) -> None:
+def install(names=None, planes_utils=None, pnp=None) -> None:
     """Register the drop-in modules in ``sys.modules`` under the reference's import names.
 
-    Only the network modules (and the pose fit) are replaced; ``warp_learn`` and ``edgeconnect`` keep resolving their
-    other sub-modules (config, online_visibility, ...) from the reference checkout on ``sys.path``.
-    ``planes_utils=True`` (or FUSG_DROPIN_PLANES_UTILS=1 in the environment) additionally routes
-    ``from warp_learn.planes_utils import to_image, warp_unwarp_planes`` (trajectory_inference.py:28-29) to the device
-    versions - explicit, because their parity with OpenCV is unpinned."""
+    By default only the four network packages are replaced; ``warp_learn``, ``edgeconnect`` and ``utils`` keep resolving
+    their other sub-modules (config, online_visibility, pnp_utils, ...) from the reference checkout on ``sys.path``.
+    ``planes_utils=True`` (or FUSG_DROPIN_PLANES_UTILS=1) additionally routes ``from warp_learn.planes_utils import
+    to_image, warp_unwarp_planes`` (trajectory_inference.py:28-29) to the device versions; ``pnp=True`` (or
+    FUSG_DROPIN_PNP=1) routes ``from utils.pnp_utils import cpc_rodr_4_angles`` (:25) to the device pose fit - both
+    explicit, because their parity with OpenCV is unpinned."""
     import os
     if planes_utils is None:
         planes_utils = os.environ.get("FUSG_DROPIN_PLANES_UTILS") == "1"
+    if pnp is None:
+        pnp = os.environ.get("FUSG_DROPIN_PNP") == "1"
     aliases = dict(_ALIASES)
     if planes_utils:
-        aliases.update(_OPT_IN_ALIASES)
+        aliases.update(_OPT_IN_ALIASES["planes_utils"])
+    if pnp:
+        aliases.update(_OPT_IN_ALIASES["pnp"])
     for alias, target in aliases.items():
         if names is not None and alias.split(".")[0] not in names:
             continue

@@ -266,11 +266,34 @@ class VehiclePipeline:
 
         return res, (lambda: ops.join_from(st, list(tensors(res))))
 
-    def compile(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None) -> "CompiledPass":
+    def compile(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None, fn=None) -> "CompiledPass":
         """Record one crop pass for inputs of `batch`'s shapes into a fusg_plan and return the object that replays it:
         `compiled.run(batch, vehicle_seeds)` gives what `self.run` gives, with one library call instead of ~370 (the
-        reference's batch-1 call pattern is bound by the interpreter, not by the GPU)."""
-        return CompiledPass(self, batch, vehicle_seeds)
+        reference's batch-1 call pattern is bound by the interpreter, not by the GPU).  `fn(batch, vehicle_seeds) -> dict of
+        tensors`: record that pass instead of `self._run` (e.g. `self._vunet_forward`: BASELINE configs[0])."""
+        return CompiledPass(self, batch, vehicle_seeds, fn)
+
+    @torch.no_grad()
+    def _vunet_forward(self, batch, vehicle_seeds=None):
+        """BASELINE configs[0]: `Vunet_fix_res.forward(y_tilde, x)` alone (vunet/models.py:461-481, mean_appearance: the
+        decoder is conditioned on the SAMPLED appearance code z_app, :476).  batch: 'vu_y' [B,3,R,R], 'vu_x' [B,6,R,R]."""
+        from . import ops
+        vu = self.vunet
+        vu.set_vehicle_seeds(vehicle_seeds)
+        # forward()'s four calls (:472-476) with the shape encoder - which draws no noise and depends on nothing else - on
+        # the side stream, as in `_run`: same launches, same noise order, same bits as `self.vunet.forward(y_tilde, x)`
+        (do, ds), join = self._side("vunet_shape", lambda: vu.forward_dec_up(batch["vu_y"]))
+        eo, es = vu.forward_enc_up(batch["vu_x"])
+        mu_app, z_app = vu.forward_enc_down(eo, es)
+        join()
+        xt, mu_shape, _ = vu.forward_dec_down(do, ds, z_app)
+        return {"x_tilde": xt, "vunet_u8": ops.to_image_u8(xt), "mu_app_0": mu_app[0], "mu_app_1": mu_app[1],
+                "mu_shape_0": mu_shape[0], "mu_shape_1": mu_shape[1]}
+
+    def vunet_forward(self, batch, vehicle_seeds=None, check: Optional[str] = "sync"):
+        """`_vunet_forward` under the pipeline's range guard (see `run`)."""
+        rng = torch.get_rng_state() if (vehicle_seeds is None and check == "sync") else None
+        return self._guarded(self._vunet_forward, (batch, vehicle_seeds), check, rng)
 
     # Range guard of the split-fp16 contraction (ops.py): the networks' own per-call checks are deferred while a pass
     # is being issued (they would synchronise the host once per network and undo the stream overlap); the pass is
@@ -738,14 +761,15 @@ class CompiledPass:
     (the VUnet's CPU-drawn sampler noise: same generator, order and shapes as the reference) refreshed before every
     replay.  The returned tensors are the plan's output buffers: the next `run` overwrites them."""
 
-    def __init__(self, pipe: "VehiclePipeline", batch: Dict[str, torch.Tensor], vehicle_seeds=None):
+    def __init__(self, pipe: "VehiclePipeline", batch: Dict[str, torch.Tensor], vehicle_seeds=None, fn=None):
         from . import _lib as L
         from . import ops
         self.pipe, self.device = pipe, pipe.device
+        self.fn = fn if fn is not None else pipe._run                          # the pass being recorded
         self.precision = ops.PRECISION                                        # recorded into every conv descriptor
         self.keys = sorted(batch.keys())
         with torch.cuda.device(self.device):
-            pipe.run(batch, vehicle_seeds=vehicle_seeds, check=None)          # warm-up: weight upload, workspaces, streams
+            pipe._guarded(self.fn, (batch, vehicle_seeds), None, None)        # warm-up: weight upload, workspaces, streams
             torch.cuda.synchronize(self.device)
             self.stream = torch.cuda.current_stream(self.device)
             self.pool = torch.cuda.MemPool()
@@ -756,7 +780,7 @@ class CompiledPass:
                 ops.RECORDER = self.rec
                 try:
                     with ops.defer_range_check(), ops.status_scope(pipe.status_word()):
-                        self.outputs = pipe._run(self.inputs, vehicle_seeds)
+                        self.outputs = self.fn(self.inputs, vehicle_seeds)
                 finally:
                     ops.RECORDER = None
                     L.check(L.lib().fusg_plan_end(self.rec.handle), "plan_end")
@@ -816,7 +840,7 @@ class CompiledPass:
             if rng is not None:
                 torch.set_rng_state(rng)
             with ops.defer_range_check(), ops.precision("f32"):
-                return self.pipe._run(batch, vehicle_seeds)
+                return self.fn(batch, vehicle_seeds)
 
 
 def synth_clip(vehicles: int, frames: int, res: int, device, seed: int = 0) -> Dict[str, torch.Tensor]:

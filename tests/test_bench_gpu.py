@@ -25,7 +25,11 @@ def test_bench_gpus2_self_spawn():
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     line = lines[0]
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+    # the field a scaling check keys on names the transport honestly: "rccl_ranks" only when RCCL carried the collectives
+    ranks_key = "dist_ranks" if env.get("FUSG_DIST_BACKEND") == "gloo" else "rccl_ranks"
+    other_key = "rccl_ranks" if ranks_key == "dist_ranks" else "dist_ranks"
+    assert line["n_gpus"] == 2 and line[ranks_key] == 2 and other_key not in line and line["value"] > 0
+    assert line["dist_backend"] == ("gloo" if ranks_key == "dist_ranks" else "nccl")
     assert set(line["precision_legs"]) >= {"f16x3", "f32"}          # (+ the bf16 leg of BASELINE configs[4])
     assert line["config"]["batch_per_gpu"] == 2 and line["scaling"] == "weak"
     assert line["per_rank_crops_per_s"]["min"] <= line["per_rank_crops_per_s"]["max"]
