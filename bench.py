@@ -635,6 +635,24 @@ def main():
                                "includes": "box crops, hourglass + argmax + pose fit, plane warps, ICN (+Lab->BGR), VUnet, "
                                            + ("EdgeConnect on every vehicle's box + its resize-back under the pasted crop, " if args.inpaint else "")
                                            + "paste-back of both composited frames; range check per frame"}
+        # clip mode of the frame driver: one vehicle clip the reference's way - the first frame through
+        # run_frame, its five future frames (trajectory_inference.py:267) through run_later_frame with the first frame's state
+        from future_urban_scene_generation_amd.pipeline import synth_later_frame
+        laters = [synth_later_frame(scene, 1 + n) for n in range(5)]
+        for _ in pipe.run_clip_frames(scene, laters, replay=True):
+            pass
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        NC = 3
+        for _ in range(NC):
+            for _ in pipe.run_clip_frames(scene, laters, replay=True):
+                pass
+        torch.cuda.synchronize()
+        cdt = (time.perf_counter() - t1) / NC
+        extra["clip_frame_mode"] = {"vehicles": FV, "frames": 6, "ms_per_clip": round(cdt * 1e3, 3), "ms_per_frame": round(cdt * 1e3 / 6, 3),
+                                    "vehicle_frames_per_s": round(FV * 6 / cdt, 1),
+                                    "what": "1 run_frame + 5 run_later_frame (no hourglass / pose fit / appearance encoder in the later "
+                                            "frames), one synchronous frame at a time, 8 vehicles on a 720 x 1280 frame"}
         del scene, scene2
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

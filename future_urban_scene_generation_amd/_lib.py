@@ -121,6 +121,10 @@ _SIGS = {
     "fusg_plan_next_slot": (C.c_int, [C.c_void_p]),
     "fusg_plan_size": (C.c_int64, [C.c_void_p]),
     "fusg_plan_run": (C.c_int, [C.c_void_p]),
+    "fusg_plan_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "fusg_plan_graph_nodes": (C.c_int64, [C.c_void_p]),
+    "fusg_plan_graph_slot": (C.c_int, [C.c_void_p]),
+    "fusg_plan_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fusg_pack_conv_sizes": (C.c_int, [C.POINTER(PackSpec), C.POINTER(PackSizes)]),
     "fusg_pack_conv_weights": (C.c_int, [C.POINTER(PackSpec)] + [C.c_void_p] * 8),
     "fusg_version": (C.c_int, []),

@@ -32,6 +32,10 @@ struct fusg_plan {
     std::vector<int> h2d_ops;                       // indices of the h2d ops
     int nslots = 0;                                 // ring depth of the pinned h2d sources (same for all h2d ops)
     long runs = 0;                                  // passes issued so far (the recording counts as one)
+    hipGraph_t graph = nullptr;                     // fusg_plan_graph_capture: the recording as ONE hipGraph (experiment)
+    hipGraphExec_t gexec = nullptr;
+    hipEvent_t gslot_ev = nullptr;                  // recorded behind every graph launch: the graph's pinned slot is free once it is reached
+    int gslot = 0;
 };
 
 namespace fusg {
@@ -57,6 +61,9 @@ extern "C" void fusg_plan_destroy(fusg_plan* p) {
     if (!p) return;
     if (g_rec == p) g_rec = nullptr;
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->gslot_ev) (void)hipEventDestroy(p->gslot_ev);
     delete p;
 }
 
@@ -146,5 +153,75 @@ extern "C" int fusg_plan_run(fusg_plan* p) {
         }
     }
     p->runs += 1;
+    return FUSG_OK;
+}
+
+
+// ---- the same recording as ONE hipGraph ---------------------------------------------------------------------------
+// Re-issues the recorded sequence under a stream capture that starts on `capture_stream` (the stream the pass was recorded
+// from: the recorded cross-stream dependencies pull the side streams into the capture and join them back) and instantiates
+// the captured graph.  Everything that may not happen under capture stays out of it: the per-slot event records of the h2d
+// ring (a captured event cannot be synchronised from the host) - the graph copies from ONE pinned slot, `slot`, and
+// fusg_plan_graph_launch orders the host against it with an event recorded OUTSIDE the graph.  The capture is ALWAYS ended,
+// also when an operation fails inside it, so a failed attempt leaves no stream in capture mode (round 3's experiment did
+// not, and torch's allocator asserted at exit).  Thread-local capture mode: other threads' HIP calls are unaffected.
+// Returns FUSG_OK, or an error whose text names the recorded operation (index, kind) that failed.
+extern "C" int fusg_plan_graph_capture(fusg_plan* p, void* capture_stream, int32_t slot) {
+    FUSG_CHECK(p && !g_rec && !p->ops.empty(), "plan_graph_capture: null / empty plan or a recording is open");
+    FUSG_CHECK(!p->gexec, "plan_graph_capture: this plan already holds a graph");
+    FUSG_CHECK(slot >= 0 && (p->nslots == 0 || slot < p->nslots), "plan_graph_capture: slot %d of %d", slot, p->nslots);
+    hipStream_t cs = (hipStream_t)capture_stream;
+    if (hipEventCreateWithFlags(&p->gslot_ev, hipEventDisableTiming) != hipSuccess) { set_error("plan_graph_capture: hipEventCreate failed"); return FUSG_ERR_LAUNCH; }
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("plan_graph_capture: hipStreamBeginCapture: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
+    int rc = FUSG_OK, bad = -1;
+    char why[256] = "";
+    for (size_t i = 0; i < p->ops.size() && rc == FUSG_OK; ++i) {
+        fusg_plan::Op& op = p->ops[i];
+        hipError_t he = hipSuccess;
+        switch (op.kind) {
+            case 0: rc = op.fn(op.stream); if (rc != FUSG_OK) snprintf(why, sizeof why, "launch closure: %s", fusg_last_error()); break;
+            case 1: he = hipEventRecord(op.ev, op.stream); break;
+            case 2: he = hipStreamWaitEvent(op.stream, op.ev, 0); break;
+            default: he = hipMemcpyAsync(op.dst, op.src + (size_t)slot * op.slot_stride, op.bytes, hipMemcpyHostToDevice, op.stream);
+        }
+        if (he != hipSuccess) { rc = FUSG_ERR_LAUNCH; snprintf(why, sizeof why, "%s", hipGetErrorString(he)); }
+        if (rc != FUSG_OK) bad = (int)i;
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cs, &g);                               // always: a failed attempt must not leave the stream capturing
+    (void)hipGetLastError();
+    if (rc != FUSG_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        set_error("plan_graph_capture: recorded operation %d (kind %d) failed under capture: %s", bad, p->ops[bad].kind, why);
+        return rc;
+    }
+    if (e != hipSuccess || !g) { set_error("plan_graph_capture: hipStreamEndCapture: %s", hipGetErrorString(e)); if (g) (void)hipGraphDestroy(g); return FUSG_ERR_LAUNCH; }
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { set_error("plan_graph_capture: hipGraphInstantiate: %s", hipGetErrorString(e)); (void)hipGraphDestroy(g); return FUSG_ERR_LAUNCH; }
+    p->graph = g; p->gexec = ge; p->gslot = slot;
+    return FUSG_OK;
+}
+
+extern "C" int64_t fusg_plan_graph_nodes(const fusg_plan* p) {
+    if (!p || !p->graph) return -1;
+    size_t n = 0;
+    if (hipGraphGetNodes(p->graph, nullptr, &n) != hipSuccess) return -1;
+    return (int64_t)n;
+}
+
+// Waits until the previous graph launch has consumed the graph's pinned slot (so the host may refill it), then returns the slot.
+extern "C" int fusg_plan_graph_slot(fusg_plan* p) {
+    if (!p || !p->gexec) { set_error("plan_graph_slot: no graph"); return -1; }
+    if (hipEventSynchronize(p->gslot_ev) != hipSuccess) { set_error("plan_graph_slot: event sync failed"); return -1; }
+    return p->gslot;
+}
+
+extern "C" int fusg_plan_graph_launch(fusg_plan* p, void* stream) {
+    FUSG_CHECK(p && p->gexec, "plan_graph_launch: no graph (fusg_plan_graph_capture first)");
+    hipError_t e = hipGraphLaunch(p->gexec, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("plan_graph_launch: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
+    if (hipEventRecord(p->gslot_ev, (hipStream_t)stream) != hipSuccess) { set_error("plan_graph_launch: event record failed"); return FUSG_ERR_LAUNCH; }
     return FUSG_OK;
 }

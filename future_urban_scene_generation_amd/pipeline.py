@@ -47,7 +47,8 @@ def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0)
     max_n = max(hi - lo for lo, hi in sizes)
     if local.is_cuda and dist.get_backend(group) == "gloo":       # rehearsal of the multi-rank path without RCCL
         local = local.cpu()
-    key = (max_n, tuple(local.shape[1:]), local.dtype, str(local.device), world, rank == dst, id(group))
+    stream_id = torch.cuda.current_stream(local.device).cuda_stream if local.is_cuda else 0     # staging buffers live on one stream
+    key = (max_n, tuple(local.shape[1:]), local.dtype, str(local.device), world, rank == dst, id(group), stream_id)
     bufs = _GATHER_BUFS.get(key)
     if bufs is None:
         pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -426,7 +427,9 @@ class VehiclePipeline:
         A pipeline built with cad=True classifies every vehicle's box crop (VGG-19, :66-69) and returns 'cad_idx' int64 [V]; with
         'kp3d_bank' float32 [n_cad, 12, 3] in the scene the pose fit uses the chosen model's keypoints (:82-88) instead of 'kp3d'.
         With an initialised process group of more than one rank the frame's vehicles are sharded over the ranks (every rank
-        passes the same scene; rank 0 returns the result, the others None; scene['shard'] = False keeps a rank on its own).
+        passes the same scene; rank 0 returns the result, the other ranks a dict holding only 'state'; scene['shard'] = False
+        keeps a rank on its own).  'state' is RANK-LOCAL then: the appearance codes and central crops of the rank's own
+        vehicles [lo, hi) - all frames of a vehicle stay on one rank, `run_later_frame` picks the shard up from it.
 
         Returns 'kp_idx' int32 [V, 12], 'kp_xy' float32 [V, 12, 2], 'pose' = list of (error, rvec [3, 1], tvec [3, 1]),
         'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom' int32 [V, 8],
@@ -444,13 +447,9 @@ class VehiclePipeline:
             V = len(scene["bboxes"])
             lo, hi = shard_range(V, rank, world)
             local = self._guarded(self._frame_local, (slice_scene(scene, lo, hi), replay), check, rng)
-            full = {}
-            for k in ("kp_idx", "icn_u8", "vunet_u8", "geom") + (("inpaint_u8",) if self.inpaint else ()) + (("cad_idx",) if self.cad is not None else ()):
-                g = gather_in_order(local[k].contiguous(), V, self.group)
-                full[k] = None if g is None else g.to(self.device)
+            out = self._frame_gather_finish(scene, local, (lo, hi, V))
             if rank != 0:
-                return None
-            out = self._frame_finish(scene, full)                 # (no 'state': the appearance codes stay on the ranks that made them)
+                return out                                        # {'state': ...}: this rank's vehicles' appearance codes stay here
         else:
             out = self._guarded(self._run_frame, (scene, replay), check, rng)
         # the reference's host epilogue of the pose fit (argmin over the four starts, sign flip): 4 x 7 numbers per vehicle
@@ -469,8 +468,24 @@ class VehiclePipeline:
         redone in exact fp32 before it is yielded, with the RNG state it was issued under."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            for scene in scenes:                                  # sharded frames: one collective phase per frame, not pipelined
-                yield self.run_frame(scene, replay=replay)
+            # sharded frames, one frame deep as well: every rank issues its shard of frame i+1 before frame i's crops are
+            # gathered; the gather and rank 0's frame-level part run on a communication stream that waits for frame i's
+            # launches only, so they overlap frame i+1's networks.  Yields `run_frame`'s sharded results (rank 0: the frame,
+            # other ranks: {'state': ...}); a scene with shard = False is not pipelined.
+            pending = None
+            for scene in scenes:
+                if not scene.get("shard", True):
+                    if pending is not None:
+                        yield self._collect_sharded(pending)
+                        pending = None
+                    yield self.run_frame(scene, replay=replay)
+                    continue
+                ticket = self._issue_sharded(scene, replay)
+                if pending is not None:
+                    yield self._collect_sharded(pending)
+                pending = ticket
+            if pending is not None:
+                yield self._collect_sharded(pending)
             return
         pending = None
         for scene in scenes:
@@ -529,9 +544,105 @@ class VehiclePipeline:
         out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
         return out
 
+    def _issue_sharded(self, scene, replay):
+        """This rank's shard of a frame, issued without waiting for it (the sharded counterpart of `_issue_frame`)."""
+        import torch.distributed as dist
+        from . import ops
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        V = len(scene["bboxes"])
+        lo, hi = shard_range(V, rank, world)
+        sub = slice_scene(scene, lo, hi)
+        guarded = ops.range_guarded()
+        rng = torch.get_rng_state() if (guarded and scene.get("vehicle_seeds") is None) else None
+        word = self.status_word() if guarded else None
+        with torch.cuda.device(self.device):
+            if guarded:
+                with ops.defer_range_check(), ops.status_scope(word):
+                    local = self._frame_local(sub, replay)
+            else:
+                local = self._frame_local(sub, replay)
+            pin = None
+            if guarded:
+                ring = self.__dict__.setdefault("_shard_pins", [])
+                pin = ring.pop() if ring else torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                pin.copy_(word[:1], non_blocking=True)
+                word.zero_()
+            ev = torch.cuda.Event()
+            ev.record()
+        return {"local": local, "pin": pin, "event": ev, "scene": scene, "sub": sub, "shard": (lo, hi, V), "rng": rng, "guarded": guarded}
+
+    def _collect_sharded(self, t):
+        from . import ops
+        from .utils.pnp_utils import select_and_flip
+        t["event"].synchronize()                                  # this frame's launches only; the next frame's are already queued
+        local = t["local"]
+        if t["guarded"]:
+            hit = int(t["pin"][0]) != 0
+            self.__dict__["_shard_pins"].append(t["pin"])
+            if hit:                                               # rare: this rank's shard again, in exact fp32 (before any collective)
+                cur = torch.get_rng_state()
+                if t["rng"] is not None:
+                    torch.set_rng_state(t["rng"])
+                with ops.defer_range_check(), ops.precision("f32"):
+                    local = self._frame_local(t["sub"], False)
+                if t["rng"] is not None:
+                    torch.set_rng_state(cur)
+                torch.cuda.synchronize(self.device)
+        main = torch.cuda.current_stream(self.device)
+        comm = self.__dict__.get("_comm_stream")
+        if comm is None:
+            comm = self.__dict__["_comm_stream"] = torch.cuda.Stream(device=self.device)
+        for v in local.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(comm)
+        with torch.cuda.device(self.device), torch.cuda.stream(comm):
+            out = self._frame_gather_finish(t["scene"], local, t["shard"])
+            if "_pose_raw" in out:
+                rv, tv, er = (x.cpu().numpy() for x in out.pop("_pose_raw"))          # waits for the communication stream only
+                out["pose"] = [select_and_flip(rv[i], tv[i], er[i]) for i in range(rv.shape[0])]
+        main.wait_stream(comm)                                    # the caller consumes the results on its own stream
+        for v in out.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(main)
+        return out
+
     def _run_frame(self, scene, replay=False):
         """One rank, every vehicle: the per-vehicle part, then the frame-level part."""
         return self._frame_finish(scene, self._frame_local(scene, replay))
+
+    GATHERED = ("kp_idx", "icn_u8", "vunet_u8", "geom")
+
+    def _gather_keys(self, first_frame: bool):
+        if not first_frame:
+            return ("icn_u8", "vunet_u8", "geom")
+        return self.GATHERED + (("inpaint_u8",) if self.inpaint else ()) + (("cad_idx",) if self.cad is not None else ())
+
+    def _gather_local(self, local, V, first_frame=True):
+        """The frame's only exchange: this rank's crops / keypoint indices / crop rows -> rank 0, in vehicle order (a few small
+        messages; RCCL gather on device tensors, gloo through the host).  Returns the full dict on rank 0, None elsewhere."""
+        import torch.distributed as dist
+        full = {}
+        for k in self._gather_keys(first_frame):
+            g = gather_in_order(local[k].contiguous(), V, self.group)
+            full[k] = None if g is None else g.to(self.device)
+        return full if dist.get_rank(self.group) == 0 else None
+
+    @staticmethod
+    def _local_state(local, shard):
+        """What `run_later_frame` needs for THIS rank's vehicles (they never move: SURVEY.md 8e)."""
+        if "mu_app_0" not in local:
+            return None
+        return {"appearance": [local["mu_app_0"], local["mu_app_1"]], "central": local["central"], "shard": tuple(shard), "sharded": True}
+
+    def _frame_gather_finish(self, scene, local, shard):
+        """Sharded first frame after the rank's local part: gather -> (rank 0) frame-level part.  Every rank gets 'state'."""
+        state = self._local_state(local, shard)
+        full = self._gather_local(local, shard[2], True)
+        if full is None:
+            return {"state": state}
+        out = self._frame_finish(scene, full)                      # (no appearance codes in `full`: they stay on their ranks)
+        out["state"] = state
+        return out
 
     @torch.no_grad()
     def _frame_local(self, scene, replay=False):
@@ -561,6 +672,9 @@ class VehiclePipeline:
                     out["inpaint_u8"] = e8()
                 if self.cad is not None:
                     out["cad_idx"] = torch.empty((0,), dtype=torch.int64, device=dev)
+                # an empty shard still hands out a (zero-vehicle) state, so that `run_later_frame` takes part in the gathers
+                out.update(mu_app_0=torch.empty((0, 128, R // 64, R // 64), device=dev), mu_app_1=torch.empty((0, 128, R // 32, R // 32), device=dev),
+                           central=e8())
                 return out
             replay = replay and ops.RECORDER is None
             cps = self.__dict__.setdefault("_frame_plans", {})
@@ -646,7 +760,8 @@ class VehiclePipeline:
             out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], out["geom"], scene["masks"], **box)       # :184-198
             out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], out["geom"], scene["masks"], **box)   # :236-250
             if "mu_app_0" in out:                                 # what `run_later_frame` renders these vehicles' future frames with
-                out["state"] = {"appearance": [out.pop("mu_app_0"), out.pop("mu_app_1")], "central": out.pop("central")}
+                out["state"] = {"appearance": [out.pop("mu_app_0"), out.pop("mu_app_1")], "central": out.pop("central"),
+                                "shard": (0, V, V), "sharded": False}
         return out
 
     # ------------------------------------------------------------------------------------------ future frames of a clip
@@ -662,10 +777,28 @@ class VehiclePipeline:
         images independent of batching); state: `run_frame(...)["state"]` of the same vehicles, same order.
         Returns 'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom'."""
         rng = torch.get_rng_state() if (check == "sync" and scene.get("vehicle_seeds") is None) else None
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 and state.get("sharded"):
+            # a clip sharded over ranks (north_star: "vehicles-in-a-frame and frames-in-a-clip shard"): every rank passes the
+            # same scene and ITS OWN state (run_frame's, rank-local); it renders its vehicles [lo, hi) from the appearance codes
+            # it kept, the uint8 crops and crop rows travel to rank 0, which pastes in vehicle order.  As for the first
+            # frame the range guard runs before the collectives.  Rank 0 returns the result, the others None.
+            lo, hi, V = state["shard"]
+            if int(scene["masks"].shape[0]) != V:
+                raise ValueError(f"run_later_frame: the state was made for a frame of {V} vehicles, the scene holds {int(scene['masks'].shape[0])}")
+            local = self._guarded(self._later_local, (slice_scene(scene, lo, hi), state), check, rng)
+            full = self._gather_local(local, V, False)
+            return None if full is None else self._later_finish(scene, full)
         return self._guarded(self._run_later_frame, (scene, state), check, rng)
 
-    @torch.no_grad()
     def _run_later_frame(self, scene, state):
+        return self._later_finish(scene, self._later_local(scene, state))
+
+    @torch.no_grad()
+    def _later_local(self, scene, state):
+        """The per-vehicle part of a later frame for the vehicles `scene` lists (all, or one rank's shard - `state` holds
+        exactly these vehicles): warp, ICN, VUnet shape half.  Returns 'icn_u8' (BGR), 'vunet_u8', 'geom'."""
         from . import frame_ops as fo
         from . import ops
         from .warp_learn import planes_utils as pu
@@ -676,11 +809,9 @@ class VehiclePipeline:
         if state["central"].shape[0] != V:
             raise ValueError(f"run_later_frame: the state holds {state['central'].shape[0]} vehicles, the scene {V}")
         with torch.cuda.device(dev):
-            back = scene.get("background", frame)
             if V == 0:
                 e8 = torch.empty((0, R, R, 3), dtype=torch.uint8, device=dev)
-                return {"icn_u8": e8, "vunet_u8": e8.clone(), "frame_icn": back.clone(), "frame_vunet": back.clone(),
-                        "geom": torch.empty((0, 8), dtype=torch.int32, device=dev)}
+                return {"icn_u8": e8, "vunet_u8": e8.clone(), "geom": torch.empty((0, 8), dtype=torch.int32, device=dev)}
             jobs = pu.warp_jobs_frame(scene["src_kp"], scene["dst_kp"], scene["src_vis"], scene["dst_vis"])
             warped = pu.warp_planes_batch(scene["src_planes"], jobs)                           # :376-381
             _, geom = fo.mask_bbox_geom(scene["masks"])
@@ -699,10 +830,33 @@ class VehiclePipeline:
 
             out = self._branches([("icn", icn), ("vunet", vunet)])
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])
-            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], geom, scene["masks"])       # :393-410
-            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], geom, scene["masks"])   # :428-445
             out["geom"] = geom
         return out
+
+    @torch.no_grad()
+    def _later_finish(self, scene, out):
+        """The frame-level part of a later frame, on the rank that holds every vehicle's crops: the ordered paste."""
+        from .warp_learn import planes_utils as pu
+        frame = scene["frame"]
+        out = dict(out)
+        with torch.cuda.device(self.device):
+            back = scene.get("background", frame)
+            if int(scene["masks"].shape[0]) == 0:
+                out["frame_icn"], out["frame_vunet"] = back.clone(), back.clone()
+                return out
+            out["frame_icn"] = pu.paste_back_device(back, out["icn_u8"], out["geom"], scene["masks"])       # :393-410
+            out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], out["geom"], scene["masks"])   # :428-445
+        return out
+
+    def run_clip_frames(self, first_scene: Dict, later_scenes, replay: bool = False):
+        """A vehicle clip the reference's way (trajectory_inference.py:55-250 then :267-450): the first frame through
+        `run_frame`, every future frame through `run_later_frame` with the first frame's state.  Generator of 1 + len(later_scenes)
+        results.  Under a process group the whole clip is sharded by vehicle: a vehicle's six frames stay on one rank."""
+        first = self.run_frame(first_scene, replay=replay)
+        state = first["state"]
+        yield first if len(first) > 1 else None
+        for sc in later_scenes:
+            yield self.run_later_frame(sc, state)
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
                  check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:
@@ -815,6 +969,36 @@ class CompiledPass:
         for ring, shapes in self.rec.noise_slots:                             # the reference's draw order
             vu._fill_noise(ring[slot], shapes, gens)
         L.check(lib.fusg_plan_run(self.rec.handle), "plan_run")
+        return self.outputs
+
+    # ---- the recording as one hipGraph: a measurement path (tools/graph_capture_probe.py), not used by the product
+    def capture_graph(self) -> int:
+        """Capture this recording into ONE hipGraph (fusg_plan_graph_capture: the library re-issues its launch closures
+        under a thread-local stream capture; no Python runs inside the capture).  Returns the graph's node count."""
+        from . import _lib as L
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            L.check(L.lib().fusg_plan_graph_capture(self.rec.handle, self.stream.cuda_stream, 0), "plan_graph_capture")
+        return int(L.lib().fusg_plan_graph_nodes(self.rec.handle))
+
+    def run_graph(self, batch, vehicle_seeds=None):
+        """`_issue` through the captured graph: inputs refreshed in place, the noise drawn into the graph's pinned slot."""
+        from . import _lib as L
+        lib = L.lib()
+        with torch.cuda.device(self.device):
+            for k in self.keys:
+                src = batch[k]
+                if src.data_ptr() != self.inputs[k].data_ptr():
+                    self.inputs[k].copy_(src, non_blocking=True)
+            slot = lib.fusg_plan_graph_slot(self.rec.handle)
+            if slot < 0:
+                L.check(-1, "plan_graph_slot")
+            vu = self.pipe.vunet
+            vu.set_vehicle_seeds(vehicle_seeds)
+            gens = vu.__dict__.get("_vehicle_gens")
+            for ring, shapes in self.rec.noise_slots:
+                vu._fill_noise(ring[slot], shapes, gens)
+            L.check(lib.fusg_plan_graph_launch(self.rec.handle, self.stream.cuda_stream), "plan_graph_launch")
         return self.outputs
 
     def run(self, batch: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
@@ -934,3 +1118,17 @@ def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 
             "dst_sketch": t8(sk_dst), "src_planes": torch.stack(planes), "src_kp": src_kp, "dst_kp": dst_kp,
             "src_vis": np.stack(src_vis), "dst_vis": np.stack(dst_vis), "kp3d": np.stack(kp3d),
             "focals": np.array([1.1 * W, 1.1 * W], np.float32), "centers": np.array([W / 2, H / 2], np.float32)}
+
+
+def synth_later_frame(scene: Dict, step: int) -> Dict:
+    """The scene of `synth_frame` one trajectory step later, for `run_later_frame`: the same vehicles (masks, first-frame planes
+    and their corner points), new plane corner points for the new pose (seeded by `step`), the source sketch as the new pose's
+    sketch, and one noise seed per (vehicle, step) when the first frame had per-vehicle seeds."""
+    import numpy as np
+    g = np.random.default_rng(1000 + step)
+    out = dict(scene)
+    out["dst_kp"] = [[np.int32(p + g.normal(0, 3.0, p.shape)) for p in veh] for veh in scene["src_kp"]]
+    out["dst_sketch"] = scene["src_sketch"]
+    if scene.get("vehicle_seeds") is not None:
+        out["vehicle_seeds"] = [int(sd) * 64 + step for sd in scene["vehicle_seeds"]]
+    return out

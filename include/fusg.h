@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 109
+#define FUSG_VERSION 110
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -444,6 +444,16 @@ int        fusg_plan_add_h2d(fusg_plan* p, void* dst, const void* src, int64_t b
 int        fusg_plan_next_slot(fusg_plan* p);
 int64_t    fusg_plan_size(const fusg_plan* p);    /* recorded operations */
 int        fusg_plan_run(fusg_plan* p);           /* re-issue the recording; asynchronous like the launches themselves */
+/* The same recording as ONE hipGraph (measurement path; the product replays plans).  fusg_plan_graph_capture
+ * re-issues the recording under a thread-local stream capture begun on `capture_stream` (the stream the pass was recorded
+ * from; the recorded dependencies fork and join the side streams) and instantiates the graph; its h2d copies read pinned
+ * ring slot `slot` only.  The capture is always ended, also on failure; the error text names the recorded operation that
+ * failed.  fusg_plan_graph_slot waits until the previous launch has consumed that slot and returns it; fill it, then
+ * fusg_plan_graph_launch(p, stream).  fusg_plan_graph_nodes: nodes of the captured graph (-1: none). */
+int        fusg_plan_graph_capture(fusg_plan* p, void* capture_stream, int32_t slot);
+int64_t    fusg_plan_graph_nodes(const fusg_plan* p);
+int        fusg_plan_graph_slot(fusg_plan* p);
+int        fusg_plan_graph_launch(fusg_plan* p, void* stream);
 
 /* ---- misc ----------------------------------------------------------------------------------- */
 

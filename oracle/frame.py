@@ -41,6 +41,44 @@ def vunet_inputs(frame: np.ndarray, vehicle_mask: np.ndarray, src_sketch: np.nda
     return x, to_tensor_pm1(np.ascontiguousarray(c[..., ::-1]))[None]
 
 
+def frame_keypoints(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> np.ndarray:
+    """Only the keypoint half of `frame_pass` (trajectory_inference.py:58-65, 75-79, 95-97): box crop -> hourglass ->
+    get_maxima -> frame pixels, float32 [V, 12, 2].  Tests use it to build a well-posed pose problem for a frame whose
+    heat-maps come from random weights: 3-D points that a known pose projects onto these very keypoints."""
+    frame = scene["frame"]
+    H, W = frame.shape[:2]
+    out = []
+    for v in range(len(scene["bboxes"])):
+        bbox = [int(t) for t in scene["bboxes"][v]]
+        (x0, y0, x1, y1), pb, _ = cv.square_crop_geometry((H, W), bbox)
+        img_bbox = cv.resize_linear_u8(cv.square_crop(frame, bbox), (res, res))
+        x = torch.from_numpy(img_bbox).permute(2, 0, 1).float().div(255)
+        x = ((x - torch.from_numpy(MEAN).view(3, 1, 1)) / torch.from_numpy(STD).view(3, 1, 1))[None]
+        kp = get_maxima(hourglass_forward(state_dicts["hg"], x)["heatmaps"][-1])[0]
+        kp[:, 0] = kp[:, 0] * (x1 - x0) + x0 - pb[0]
+        kp[:, 1] = kp[:, 1] * (y1 - y0) + y0 - pb[1]
+        out.append(kp.astype(np.float32))
+    return np.stack(out)
+
+
+def well_posed_kp3d(kp_xy: np.ndarray, focals, centers, seed: int = 0, noise: float = 0.01) -> np.ndarray:
+    """3-D model points [V, 12, 3] (float32) that a seeded pose near one of the pose fit's start rotations projects onto
+    `kp_xy` [V, 12, 2] (pin-hole model of utils/cpc.py: p2 = f * (R X + t).xy / (R X + t).z + c), each keypoint at its own
+    seeded depth, plus `noise` metres of perturbation so that the fit's minimum has a non-zero residual (as real
+    detections have).  A problem with a sharp, unique minimum - unlike random 3-D points under random-weight keypoints."""
+    g = np.random.default_rng(seed)
+    f, c = np.asarray(focals, np.float64).reshape(2), np.asarray(centers, np.float64).reshape(2)
+    out = []
+    for v in range(kp_xy.shape[0]):
+        r = pnp.START_RVECS[(seed + v) % 4].astype(np.float64) + g.normal(0, 0.2, 3)
+        t = np.array([g.uniform(-2, 2), g.uniform(-1, 1), g.uniform(9, 20)])
+        z = t[2] + g.uniform(-2.0, 2.0, 12)
+        pc = np.concatenate([(kp_xy[v].astype(np.float64) - c) / f * z[:, None], z[:, None]], 1)
+        X = (pnp.rodrigues(r).astype(np.float64).T @ (pc - t).T).T
+        out.append((X + g.normal(0, noise, X.shape)).astype(np.float32))
+    return np.stack(out)
+
+
 def frame_pass(state_dicts: Dict[str, dict], scene: Dict, res: int = 256) -> Dict:
     """scene: the dict of pipeline.synth_frame with every array on the host (numpy).  Returns what run_frame returns
     (numpy), plus the intermediates the chain test compares: 'hg_x', 'icn_x', 'vu_x', 'vu_y', 'warped'."""

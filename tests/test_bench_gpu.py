@@ -48,7 +48,9 @@ def test_run_frame_sharded_over_two_ranks():
     the box's card) - 5 vehicles as shards of 3 + 2, then 1 vehicle (rank 1's shard empty) - gives rank 0 what its own
     unsharded call gives: keypoints and crop rows bit for bit, crops and composited frames to the last place (a shard is a
     smaller batch: other split-K factors), poses alike (tests/frame_shard_worker.py; `... inpaint` on its command line adds EdgeConnect,
-    whose merged crops are gathered as well - run by hand, left out of the suite for its time)."""
+    whose merged crops are gathered as well - run by hand, left out of the suite for its time).  Round 4: the CLIP is sharded too -
+    every rank keeps a rank-local state, `run_later_frame` renders the next frame from it on the same shards (== the unsharded
+    later frame within the recorded bars), and sharded `run_frames` keeps one frame in flight (== `run_frame`, bit for bit)."""
     if torch.cuda.is_initialized():
         pytest.skip("this process has initialised HIP: worker processes are started only from a process that has not")
     import socket
@@ -64,3 +66,9 @@ def test_run_frame_sharded_over_two_ranks():
         assert p.returncode == 0, se[-2000:]
     assert "SHARD_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
     sys.stdout.write(outs[0][0])
+    # the differences the worker observed (sharded vs unsharded: first frame, later frame of the clip) go into the parity log
+    from conftest import record
+    obs = [ln for ln in outs[0][0].splitlines() if ln.startswith("OBS ")]
+    assert obs
+    for k, v in json.loads(obs[-1][4:]).items():
+        record("shard_" + k, v)

@@ -158,14 +158,57 @@ def test_run_frame_against_the_oracle_chain():
     for v in range(V):
         e, rv, tv = got["pose"][v]
         oe, orv, otv = ref["pose"][v]
-        # (random-weight heat-maps give keypoints no pose explains: the fit is ill-conditioned here and only compared
-        # where both reached the same minimum; tests/test_gpu_pnp.py holds the well-posed parity cases)
+        # (random 3-D points under random-weight keypoints: no pose explains them, the fit is ill-conditioned and only
+        # compared where both reached the same minimum; test_run_frame_pose_chain_is_asserted_for_every_vehicle below
+        # holds the well-posed, unconditional form)
         if not (np.isfinite(e) and np.isfinite(oe) and float(oe) > 0):
             continue
         rel = abs(float(e) / float(oe) - 1)
         record("frame_pose_err_rel", rel)
         if rel < 1e-3:                                                            # same minimum reached: same pose
             assert np.abs(opnp.rodrigues(rv) - opnp.rodrigues(orv)).max() < 1e-3 and np.abs(tv - otv).max() < 1e-2 * max(1.0, np.abs(otv).max())
+
+
+@pytest.mark.gpu
+def test_run_frame_pose_chain_is_asserted_for_every_vehicle():
+    """VERDICT r3 #3a: kp_idx -> keypoints_to_frame -> cpc_fit_device -> select_and_flip end to end, asserted for EVERY
+    vehicle (trajectory_inference.py:94-105).  The scene's 3-D keypoints are built so that a known pose projects them onto
+    the ORACLE's predicted keypoints (oracle.frame.well_posed_kp3d: seeded pose near a start rotation, seeded depths, 1 cm
+    of noise) - a fit with one sharp minimum, where the ill-posed random scene above left the comparison conditional.
+    Bars: rotation matrix 1e-4 absolute, translation 1e-4 relative, error 1e-3 relative, against oracle.frame_pass."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_frame
+    from future_urban_scene_generation_amd import ops
+    from oracle import pnp as opnp
+    ops.set_precision("f16x3")
+    V = 4
+    sds = {n: synth_sd(n) for n in ("hg", "icn", "vunet")}
+    pipe = VehiclePipeline(DEV, state_dicts=sds)
+    sc = synth_frame(V, (360, 640), DEV, seed=31)
+    sc["vehicle_seeds"] = [90 + v for v in range(V)]
+    cpu = _scene_cpu(sc)
+    kp = oracle.frame.frame_keypoints(sds, cpu)
+    sc["kp3d"] = oracle.frame.well_posed_kp3d(kp, sc["focals"], sc["centers"], seed=2)
+    cpu = _scene_cpu(sc)
+    got = pipe.run_frame(sc)
+    assert np.array_equal(got["kp_xy"].cpu().numpy(), kp)
+    worst = [0.0, 0.0, 0.0]
+    for v in range(V):
+        oe, orv, otv = opnp.cpc_rodr_4_angles(cpu["focals"], cpu["centers"], kp[v], cpu["kp3d"][v])[:3]   # :104-105 on the oracle's keypoints
+        e, rv, tv = got["pose"][v]
+        assert np.isfinite(e) and np.isfinite(oe) and float(oe) > 0, (v, e, oe)
+        d_r = float(np.abs(opnp.rodrigues(rv) - opnp.rodrigues(orv)).max())
+        d_t = float(np.abs(np.asarray(tv).ravel() - np.asarray(otv).ravel()).max() / np.abs(otv).max())
+        d_e = abs(float(e) / float(oe) - 1)
+        worst = [max(a, b) for a, b in zip(worst, (d_r, d_t, d_e))]
+        assert d_r <= 1e-4 and d_t <= 1e-4 and d_e <= 1e-3, (v, d_r, d_t, d_e)
+        assert float(np.asarray(tv).ravel()[2]) > 0                                # in front of the camera (:122-128)
+    record("frame_pose_chain_rot_abs", worst[0])
+    record("frame_pose_chain_t_rel", worst[1])
+    record("frame_pose_chain_err_rel", worst[2])
+    # the pipelined / recorded forms hand out the same poses, bit for bit
+    seq = list(pipe.run_frames([sc, sc]))
+    for a, b in zip(seq[1]["pose"], got["pose"]):
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
 
 
 @pytest.mark.gpu
@@ -432,3 +475,35 @@ def test_run_later_frame_matches_the_oracle():
         assert torch.equal(again[k], got[k]), k
     with pytest.raises(ValueError):
         pipe.run_later_frame(synth_frame(1, (360, 640), DEV, seed=43), f0["state"])
+
+
+@pytest.mark.gpu
+def test_configs0_vunet_forward_pass_and_its_replay():
+    """BASELINE configs[0] (`Vunet_fix_res.forward` alone): the pipeline's form of the call (shape encoder on the side stream)
+    gives the module's own `forward(y_tilde, x)` bit for bit under the same seed - the decoder conditioned on the SAMPLED
+    appearance code z_app (vunet/models.py:476), unlike traj_test's mu_app - and a recorded-plan replay of it gives the
+    same bits again, with fresh noise per replay drawn in the reference's order; against the oracle within the VUnet bar."""
+    from future_urban_scene_generation_amd.pipeline import VehiclePipeline, synth_batch
+    from future_urban_scene_generation_amd import ops
+    ops.set_precision("f16x3")
+    sds = {n: synth_sd(n) for n in ("hg", "icn", "vunet")}
+    pipe = VehiclePipeline(DEV, state_dicts=sds)
+    b = synth_batch(1, 256, DEV, seed=5)
+    b1 = {"vu_x": b["vu_x"], "vu_y": b["vu_y"]}
+    torch.manual_seed(41)
+    xt, mu_app, mu_shape = pipe.vunet.forward(b1["vu_y"], b1["vu_x"])
+    torch.manual_seed(41)
+    got = pipe.vunet_forward(b1)
+    assert torch.equal(got["x_tilde"], xt) and torch.equal(got["mu_app_1"], mu_app[1]) and torch.equal(got["mu_shape_1"], mu_shape[1])
+    cp = pipe.compile(b1, None, fn=pipe._vunet_forward)
+    torch.manual_seed(41)
+    rep = {k: v.clone() for k, v in cp.run(b1).items()}
+    assert torch.equal(rep["x_tilde"], xt) and torch.equal(rep["vunet_u8"], got["vunet_u8"])
+    torch.manual_seed(42)
+    rep2 = cp.run(b1)
+    assert not torch.equal(rep2["x_tilde"], xt)                                   # other noise, other image
+    torch.manual_seed(41)
+    ref = oracle.vunet_forward(sds["vunet"], b1["vu_y"].cpu(), b1["vu_x"].cpu())[0]
+    rel = float((xt.cpu().double() - ref.double()).abs().max() / ref.abs().max())
+    record("configs0_vunet_forward_rel_err", rel)
+    assert rel < 2e-5
