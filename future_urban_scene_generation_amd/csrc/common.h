@@ -56,7 +56,7 @@ hipError_t ensure_dyn_lds(const void* fn, int bytes);
 
 // Development switches, read from the environment ONCE (first use): FUSG_NO_VEC_EPI, FUSG_NO_HALO,
 // FUSG_HALO_MINWG, FUSG_HALO_BN, FUSG_NO_TOUCH (tools/README.md).  (api.hip)
-struct EnvSwitches { bool no_vec_epi, no_halo, no_touch, no_pointwise, no_ksplit; long halo_minwg; int halo_bn; };
+struct EnvSwitches { bool no_vec_epi, no_halo, no_touch, no_pointwise, no_ksplit; long halo_minwg; int halo_bn, small_maxhw; };
 const EnvSwitches& env_switches();
 
 // ---- recorded passes (plan.hip) ----------------------------------------------------------------------------------

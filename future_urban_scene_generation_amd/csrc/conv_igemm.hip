@@ -1,7 +1,9 @@
 // Host side of the fused implicit-GEMM convolution: descriptor validation, tile / split-K
 // heuristics, launch, and the deterministic split-K slab reduction.  Kernel: conv_kernel.h.
+#include <stdlib.h>
 #include <mutex>
 #include "conv_kernel_tapunit.h"
+#include "conv_kernel_small.h"
 
 namespace fusg {
 
@@ -141,9 +143,66 @@ const float* zero_line() {
     return z[dev];
 }
 
+// Does this launch take the small-spatial kernel (conv_kernel_small.h), and with which K ranges?  Shared by the planner
+// (workspace size) and the launcher.
+struct SmallCfg { int nimg, rpi, rpi_shift, RIN, WIN, NPIX, nchw, ksplit, nch32, ntaps; };
+static bool small_cfg(const fusg_conv_desc* d, int precision, SmallCfg* out) {
+    // (FUSG_NO_SMALL is read per call: tests and the A/B tools flip it at run time)
+    if (getenv("FUSG_NO_SMALL") != nullptr || env_switches().no_halo) return false;
+    const int nphase = d->nphase > 0 ? d->nphase : 1;
+    if (precision != FUSG_PREC_F16X3 || nphase != 1 || d->kh < 1 || d->kw < 1 || d->kh > 3 || d->kw > 3 || d->dil != 1 ||
+        d->pad_mode != FUSG_PAD_ZERO || d->upsample != 0 || (d->stride != 1 && d->stride != 2) || d->tile_list || d->stats_out ||
+        (d->q_oy | d->q_ox) != 0 || !d->wfrag || (((uintptr_t)d->wfrag) & 15) != 0 || (d->wfrag_order != 0 && d->wfrag_order != 1))
+        return false;
+    const int ntaps = d->kh * d->kw;
+    if (d->c0k <= 0 || d->c0k % 32 || d->k_pad % ntaps) return false;
+    const int ctot = d->k_pad / ntaps, c1k = ctot - d->c0k;
+    if (c1k < 0 || c1k % 32 || (c1k > 0 && !d->src1.data)) return false;
+    if (d->wfrag_order == 1 && !(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1)) return false;
+    const int Ho = d->qh, Wo = d->qw, hw = Ho * Wo;
+    if (hw > env_switches().small_maxhw) return false;
+    SmallCfg c;
+    if (hw >= SMALL_ROWS) {
+        if (hw % SMALL_ROWS || SMALL_ROWS % Wo) return false;
+        c.nimg = 1; c.rpi = SMALL_ROWS;
+        c.RIN = (SMALL_ROWS / Wo - 1) * d->stride + d->kh;
+    } else {
+        if (SMALL_ROWS % hw) return false;
+        c.nimg = SMALL_ROWS / hw; c.rpi = hw;
+        c.RIN = (Ho - 1) * d->stride + d->kh;
+    }
+    c.rpi_shift = 0;
+    while ((1 << c.rpi_shift) < c.rpi) ++c.rpi_shift;
+    if ((1 << c.rpi_shift) != c.rpi) return false;
+    c.WIN = (Wo - 1) * d->stride + d->kw;
+    c.NPIX = c.nimg * c.RIN * c.WIN;
+    if (c.NPIX > SMALL_MAXPIX) return false;
+    c.nch32 = ctot / 32; c.ntaps = ntaps;
+    // chunks per K range: the staged image must fit (<= 96 KiB) and a wave should not need more than two rounds of weights
+    int nchw = (96 * 1024) / (c.NPIX * 128);
+    const int by_rounds = (2 * 4 * SMALL_NS) / ntaps;
+    if (by_rounds < nchw) nchw = by_rounds;
+    if (nchw < 1) return false;
+    if (d->ksplit == 1 && nchw < c.nch32) return false;            // the caller wants K whole
+    if (nchw > c.nch32) nchw = c.nch32;
+    c.ksplit = (c.nch32 + nchw - 1) / nchw;
+    c.nchw = (c.nch32 + c.ksplit - 1) / c.ksplit;
+    c.ksplit = (c.nch32 + c.nchw - 1) / c.nchw;                    // every range non-empty
+    *out = c;
+    return true;
+}
+
 static int64_t plan_impl(fusg_conv_desc* d) {
     const long M = (long)d->src0.n * d->qh * d->qw;
     const int nphase = d->nphase > 0 ? d->nphase : 1;
+    {
+        SmallCfg sc;
+        if (small_cfg(d, d->precision == FUSG_PREC_BF16 ? FUSG_PREC_F16X3 : d->precision, &sc)) {
+            d->tile = FUSG_TILE_128x32;
+            d->ksplit = sc.ksplit;
+            return sc.ksplit > 1 ? (int64_t)sc.ksplit * M * d->cout_pad * (int64_t)sizeof(float) : 0;
+        }
+    }
     if (d->tile == FUSG_TILE_AUTO) {
         int bn = d->cout_pad >= 128 && d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
         int bm = 128;
@@ -349,6 +408,53 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
                          d->k_pad % (d->kh * d->kw) == 0 && d->wfrag != nullptr && (((uintptr_t)d->wfrag) & 15) == 0 &&
                          !env_switches().no_halo && (d->q_oy | d->q_ox) == 0;
+    // small images (<= 16 x 16): the latency-built kernel of conv_kernel_small.h
+    {
+        SmallCfg sc;
+        fusg_conv_desc probe = *din;                    // (plan_impl above has already overwritten d->ksplit / d->tile)
+        if (small_cfg(&probe, d->precision, &sc) && sc.ksplit == d->ksplit) {
+            SmallK h;
+            memset(&h, 0, sizeof(h));
+            h.c = k;
+            h.kh = d->kh; h.kw = d->kw; h.pad_h = d->pad_h; h.pad_w = d->pad_w; h.stride = d->stride;
+            h.nch0 = d->c0k / 32; h.nch32 = sc.nch32; h.ntaps = sc.ntaps;
+            h.wfrag = (const _Float16*)d->wfrag; h.nt32 = d->cout_pad / 32;
+            if (d->wfrag_order == 1) {                  // parity-quadrant slab order of the stride-2 3x3 layers (pack.s2d_tap_order)
+                int slab = 0;
+                for (int q = 0; q < 4; ++q)
+                    for (int ky = 0; ky < 3; ++ky) {
+                        if (((ky - 1) & 1) != (q >> 1)) continue;
+                        for (int kx = 0; kx < 3; ++kx)
+                            if (((kx - 1) & 1) == (q & 1)) h.tapslab[ky * 3 + kx] = slab++;
+                    }
+            } else {
+                for (int tp = 0; tp < sc.ntaps; ++tp) h.tapslab[tp] = tp;
+            }
+            h.nchw = sc.nchw; h.nimg = sc.nimg; h.rpi = sc.rpi; h.rpi_shift = sc.rpi_shift;
+            h.RIN = sc.RIN; h.WIN = sc.WIN; h.NPIX = sc.NPIX;
+            auto magic = [](int dv) -> unsigned { return dv < 2 ? 0u : (unsigned)(((1UL << 32) + (unsigned long)dv - 1) / (unsigned long)dv); };
+            h.m_wo = magic(d->qw); h.m_hw = magic(d->qh * d->qw); h.m_win = magic(sc.WIN); h.m_rw = magic(sc.RIN * sc.WIN);
+            h.m_npix = magic(sc.NPIX); h.m_taps = magic(sc.ntaps); h.m_ihw = magic((int)(x0.h * x0.w));
+            // (the reciprocals are exact while dividend * divisor < 2^32: the largest dividend is a source pixel index)
+            if ((long)x0.n * x0.h * x0.w * (x0.h * x0.w) < (1L << 32) && Ml * (long)(d->qh * d->qw) < (1L << 32)) {
+                h.c.MT = (int)((Ml + SMALL_ROWS - 1) / SMALL_ROWS); h.c.NT = d->cout_pad / 32;
+                h.c.ksplit = sc.ksplit;
+                dim3 sgrid(h.c.MT * h.c.NT, 1, sc.ksplit);
+                e = launch_small(h, sgrid, s, pk);
+                if (e != hipSuccess) { set_error("conv2d small-image launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+                if (sc.ksplit > 1) {
+                    const long total = (long)k.M * (k.Cout_pad >> 2);
+                    ConvK kr = h.c;
+                    hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kr, 1);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) { set_error("conv2d split-K reduce launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+                }
+                note_conv_kernel(FUSG_CONV_SMALL);
+                prof_end(0, s);
+                return FUSG_OK;
+            }
+        }
+    }
     // pointwise from <= 8 channels: the streaming VALU kernel above (split-fp16 precision only: the exact-fp32 path keeps
     // its one kernel family; the result is the fp32 kernel's, bit for bit)
     if (d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->upsample == 0 && !has1 &&

@@ -511,7 +511,14 @@ def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> 
             and c1.c0k == x.shape[1] and x.shape[1] % 32 == 0 and c1.c1k == 0 and c2.pad == 1 and c2.stride == 1):
         return False
     lim = _os.environ.get("FUSG_BNECK_MAXHW")
-    return lim is None or max(x.shape[2], x.shape[3]) <= int(lim)
+    if lim is not None and max(x.shape[2], x.shape[3]) > int(lim):
+        return False
+    # levels below BNECK_MINHW pixels a side run as three launches of the small-image kernel (csrc/conv_kernel_small.h): one
+    # workgroup per image walking 48 K-steps in series (25 us) against three ~5 us launches
+    return max(x.shape[2], x.shape[3]) >= BNECK_MINHW or _env_set("FUSG_NO_SMALL")
+
+
+BNECK_MINHW = int(_os.environ.get("FUSG_BNECK_MINHW", "0"))
 
 
 def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:

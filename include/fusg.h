@@ -464,7 +464,8 @@ const char* fusg_last_error(void);
  * (few-channel stems), 5 halo kernel in single-pass bf16; -1 none yet. */
 enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 2, FUSG_CONV_HALO_S2D = 3,
        FUSG_CONV_TAPUNIT = 4, FUSG_CONV_HALO_BF16 = 5, FUSG_CONV_BNECK = 6 /* fusg_hg_bottleneck */,
-       FUSG_CONV_POINTWISE = 7 /* 1x1 from <= 8 channels: streaming fp32 FMA kernel, no matrix cores */ };
+       FUSG_CONV_POINTWISE = 7 /* 1x1 from <= 8 channels: streaming fp32 FMA kernel, no matrix cores */,
+       FUSG_CONV_SMALL = 8 /* images of <= 16 x 16 pixels: latency-built split-fp16 kernel (csrc/conv_kernel_small.h) */ };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their

@@ -795,3 +795,111 @@ def test_hg_bottleneck_fused_is_deterministic(precision):
                 _bneck_unfused(p, x, r)                      # other kernels in between (different LDS contents)
             got = ops.bottleneck(p, x, r)
             assert torch.equal(got, first), (planes, it)
+
+
+# ---- the small-image kernel (csrc/conv_kernel_small.h): images of <= 16 x 16 pixels -------------------------------
+SMALL = [  # B, c0, c1, cout, k, stride, H, W, pre_op, residual, store
+    (32, 128, 0, 128, 3, 1, 8, 8, "elu", True, "normal"),        # VUnet Residual at 8 x 8: 32 rows = half an image
+    (32, 128, 0, 128, 3, 1, 4, 4, "elu", True, "normal"),        # two whole images per workgroup
+    (32, 512, 512, 512, 3, 1, 2, 2, "elu", True, "normal"),      # AR block residual_k: eight images per workgroup, K ranges + reduce
+    (32, 512, 0, 128, 3, 1, 2, 2, "none", False, "normal"),      # AR block sampler
+    (5, 128, 128, 128, 3, 1, 4, 4, "elu", True, "normal"),       # ragged: M = 80, the last workgroup half empty; two sources
+    (1, 128, 0, 128, 3, 1, 4, 4, "elu", True, "normal"),         # the reference's batch 1: M = 16
+    (3, 128, 0, 512, 1, 1, 2, 2, "elu", False, "normal"),        # NiN 128 -> 512, M = 12
+    (4, 256, 0, 128, 1, 1, 8, 8, "none", False, "normal"),
+    (4, 128, 0, 128, 3, 2, 16, 16, "none", False, "normal"),     # DownSample 16 -> 8 (parity-quadrant weight order)
+    (4, 128, 0, 128, 3, 2, 8, 8, "none", False, "normal"),       # 8 -> 4
+    (4, 128, 0, 512, 3, 1, 4, 4, "none", False, "d2s"),          # UpSample('subpixel'): DepthToSpace store
+    (4, 128, 0, 128, 3, 1, 8, 8, "elu", False, "s2d"),           # SpaceToDepth store
+    (4, 128, 0, 128, 3, 1, 16, 16, "elu", True, "normal"),       # 16 x 16: two image rows per workgroup
+    (4, 256, 0, 128, 1, 1, 4, 4, "affine_relu", False, "normal"),   # hourglass Bottleneck conv1 (bn1 + ReLU on load)
+    (4, 128, 0, 256, 1, 1, 4, 4, "relu", True, "normal"),        # hourglass Bottleneck conv3 + residual
+    (2, 128, 0, 128, 3, 1, 8, 16, "elu", True, "normal"),        # non-square: Wo = 16
+]
+
+
+def _d2s(x):       # DCR: out[b, c, 2h+i, 2w+j] = in[b, (2i+j) C + c, h, w]
+    b, c4, h, w = x.shape
+    c = c4 // 4
+    return x.view(b, 2, 2, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(b, c, 2 * h, 2 * w)
+
+
+def _s2d(x):
+    b, c, h, w = x.shape
+    return x.view(b, c, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(b, 4 * c, h // 2, w // 2)
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,k,stride,H,W,pre,res,store", SMALL)
+def test_small_image_kernel(B, c0, c1, cout, k, stride, H, W, pre, res, store, precision):
+    """Every geometry the small-image kernel takes (rows of one image / whole images per workgroup, ragged M, two sources, K
+    ranges over workgroups with the slab reduce, both weight slab orders, every pre-op, DepthToSpace / SpaceToDepth stores,
+    residual) against torch (float64) on the CPU; on f16x3 the launch must really be that kernel, and it must agree with the
+    launch it replaces (FUSG_NO_SMALL, read per call)."""
+    cin = c0 + c1
+    x0 = _rand(B, c0, H, W, seed=1)
+    x1 = _rand(B, c1, H, W, seed=2) if c1 else None
+    w = _rand(cout, cin, k, k, seed=3, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=4)
+    pad = k // 2
+    plan = pack.pack_conv(w, b, c_split=(c0, c1) if c1 else None, stride=stride, pad=pad)
+    xc = torch.cat([x0, x1], 1) if c1 else x0
+    sc = sh = None
+    if pre == "elu":
+        xin, pre_op = F.elu(xc), L.PRE_ELU
+    elif pre == "relu":
+        xin, pre_op = F.relu(xc), L.PRE_RELU
+    elif pre == "affine_relu":
+        sc, sh = _rand(cin, seed=5), _rand(cin, seed=6)
+        xin, pre_op = F.relu(xc * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), L.PRE_AFFINE_RELU
+    else:
+        xin, pre_op = xc, L.PRE_NONE
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad).float()
+    a0 = _nhwc(x0)
+    kw = dict(pre_op=pre_op)
+    if sc is not None:
+        kw["pre"] = (sc.to(dev()), sh.to(dev()))
+    if res:
+        rr = x0 if cout == c0 and stride == 1 else _rand(*ref.shape, seed=7)
+        ref = ref + rr
+        kw["res0"] = a0 if rr is x0 else _nhwc(rr)
+    if store == "d2s":
+        ref, kw["store"] = _d2s(ref), L.STORE_D2S
+    elif store == "s2d":
+        ref, kw["store"] = _s2d(ref), L.STORE_S2D
+    got = ops.conv(plan, a0, _nhwc(x1) if c1 else None, **kw)
+    if precision == "f16x3":
+        assert ops.last_conv_kernel() == 8, ops.last_conv_kernel()
+        import os
+        os.environ["FUSG_NO_SMALL"] = "1"                          # the launches it replaces: generic gather (+ split-K reduce) / halo kernel
+        try:
+            old = ops.conv(plan, a0, _nhwc(x1) if c1 else None, **kw)
+            assert ops.last_conv_kernel() != 8
+        finally:
+            del os.environ["FUSG_NO_SMALL"]
+        _close(got, old, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert tuple(got.shape) == tuple(ref.shape)
+    _close(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    assert not ops.range_exceeded(dev())
+    # into a channel slice of a wider buffer (the AR block's sampler means) and as a standard NCHW result
+    if store == "normal" and not res:
+        wide = ops.nhwc_empty(B, cout + 64, ref.shape[2], ref.shape[3], dev(), zero=True)
+        ops.conv(plan, a0, _nhwc(x1) if c1 else None, out=wide, out_c_off=32, **kw)
+        _close(wide[:, 32:32 + cout], ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+        assert float(wide[:, :32].abs().max()) == 0.0 and float(wide[:, 32 + cout:].abs().max()) == 0.0
+        _close(ops.conv(plan, a0, _nhwc(x1) if c1 else None, nchw_out=True, **kw), ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+
+
+def test_small_image_kernel_range_guard_and_determinism(precision):
+    if precision != "f16x3":
+        pytest.skip("f16x3 only")
+    x = _rand(8, 128, 4, 4, seed=1)
+    w = _rand(128, 128, 3, 3, seed=2, scale=0.03)
+    plan = pack.pack_conv(w, None, pad=1)
+    a = _nhwc(x)
+    y1 = ops.conv(plan, a, pre_op=L.PRE_ELU)
+    assert ops.last_conv_kernel() == 8
+    assert torch.equal(y1, ops.conv(plan, a, pre_op=L.PRE_ELU))
+    assert not ops.range_exceeded(dev())
+    x[3, 17, 2, 1] = 7.0e4                                        # outside the split's range: the status word, not a clamp
+    ops.conv(plan, _nhwc(x))
+    assert ops.range_exceeded(dev())

@@ -135,6 +135,10 @@ def measure(B=1):
     torch, ops, pipe, batch, dev = _setup(B)
     from future_urban_scene_generation_amd import _lib as L
     out = {"batch": B}
+    # (everything on a stream of our own: the legacy null stream cannot be captured, and a capture elsewhere forbids launches on it)
+    own = torch.cuda.Stream()
+    own.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(own)
     for tag, streams in (("one_stream", "0"), ("streams", "1")):
         os.environ["FUSG_STREAMS"] = streams
         for _ in range(3):
@@ -172,9 +176,10 @@ def measure(B=1):
             torch.cuda.synchronize()
             r["graph_equals_plan_bits"] = all(torch.equal(a[k], b[k]) for k in a)
             r["graph_replay_ms"] = lat(lambda: cp.run_graph(batch, None))
-        except L.FusgError as e:
-            r["graph_error"] = str(e)[:400]
+        except BaseException as e:
+            r["graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:600])
         out[tag] = r
+        print("PARTIAL " + json.dumps({tag: r}), flush=True)
         del cp
     out["columns"] = "[back-to-back ms per pass, median ms of one pass waited for]"
     print("MEASURE " + json.dumps(out), flush=True)
@@ -193,7 +198,7 @@ def main():
     for B in (1, 8):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "measure", str(B)], capture_output=True, text=True, timeout=600)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("MEASURE ")]
-        print(lines[-1] if lines else "MEASURE " + json.dumps({"batch": B, "rc": r.returncode, "stderr": r.stderr[-800:]}), flush=True)
+        print(lines[-1] if lines else "MEASURE " + json.dumps({"batch": B, "rc": r.returncode, "stdout": r.stdout[-1500:], "stderr": r.stderr[-3000:]}), flush=True)
 
 
 if __name__ == "__main__":
