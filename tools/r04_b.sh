@@ -22,3 +22,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('bneck_minhw $mh', d['value'], r['frac'], r['conv_ms_per_step'], r['launches_per_step'])"
 done
 timeout -k 10 300 python tools/graph_capture_probe.py measure 1 > $out/graph_measure_b1.log 2>&1; echo "measure rc=$?"; tail -c 3000 $out/graph_measure_b1.log
+timeout -k 10 200 python tools/copy_sites.py 32 > $out/copy_sites.txt 2>&1; echo "copy_sites rc=$?"; head -40 $out/copy_sites.txt
+timeout -k 10 600 python -m pytest tests/test_bench_gpu.py -x -q -m gpu > $out/bench_gpu_tests.log 2>&1; echo "bench_gpu tests rc=$?"; tail -5 $out/bench_gpu_tests.log; grep -h "^OBS\|diff\|MISMATCH" $out/bench_gpu_tests.log | head
+cp gpurun_out/parity_observed.json $out/parity_observed_bench_gpu.json 2>/dev/null
