@@ -40,7 +40,7 @@ const EnvSwitches& env_switches() {
         s.no_touch = getenv("FUSG_NO_TOUCH") != nullptr;
         s.no_ksplit = getenv("FUSG_NO_KSPLIT") != nullptr;        // narrow halo tiles with the M split over the waves (rounds 1-2)
         s.no_pointwise = getenv("FUSG_NO_POINTWISE") != nullptr;  // 1x1 from <= 8 channels on the tap-unit MFMA kernel again          // no L2 warm-up of the weights (conv_kernel.h, l2_touch)
-        s.small_maxhw = getenv("FUSG_SMALL_MAXHW") ? atoi(getenv("FUSG_SMALL_MAXHW")) : 256;   // largest Ho * Wo it takes
+        s.small_maxhw = getenv("FUSG_SMALL_MAXHW") ? atoi(getenv("FUSG_SMALL_MAXHW")) : 64;   // largest Ho * Wo it takes
         s.halo_minwg = getenv("FUSG_HALO_MINWG") ? atol(getenv("FUSG_HALO_MINWG")) : 512;
         s.halo_bn = getenv("FUSG_HALO_BN") ? atoi(getenv("FUSG_HALO_BN")) : 0;
         return s;

@@ -188,6 +188,10 @@ static bool small_cfg(const fusg_conv_desc* d, int precision, SmallCfg* out) {
     c.ksplit = (c.nch32 + nchw - 1) / nchw;
     c.nchw = (c.nch32 + c.ksplit - 1) / c.ksplit;
     c.ksplit = (c.nch32 + c.nchw - 1) / c.nchw;                    // every range non-empty
+    // K ranges over workgroups (+ the slab reduce) are implemented and tested, but measured SLOWER than the generic gather
+    // they would replace (profiles/r04_ab_experiments.txt: 1024 -> 512 k3 at 4 x 4, B = 32: 75.6 vs 41.6 us - sixteen row
+    // tiles each stream the 18.9 MB of weights; 512 -> 128: 20.6 vs 16.5 us): FUSG_SMALL_KSPLIT=1 lets them through
+    if (c.ksplit > 1 && getenv("FUSG_SMALL_KSPLIT") == nullptr) return false;
     *out = c;
     return true;
 }
@@ -425,10 +429,10 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
                     for (int ky = 0; ky < 3; ++ky) {
                         if (((ky - 1) & 1) != (q >> 1)) continue;
                         for (int kx = 0; kx < 3; ++kx)
-                            if (((kx - 1) & 1) == (q & 1)) h.tapslab[ky * 3 + kx] = slab++;
+                            if (((kx - 1) & 1) == (q & 1)) h.tapslab |= (unsigned long long)(slab++) << (4 * (ky * 3 + kx));
                     }
             } else {
-                for (int tp = 0; tp < sc.ntaps; ++tp) h.tapslab[tp] = tp;
+                for (int tp = 0; tp < sc.ntaps; ++tp) h.tapslab |= (unsigned long long)tp << (4 * tp);
             }
             h.nchw = sc.nchw; h.nimg = sc.nimg; h.rpi = sc.rpi; h.rpi_shift = sc.rpi_shift;
             h.RIN = sc.RIN; h.WIN = sc.WIN; h.NPIX = sc.NPIX;

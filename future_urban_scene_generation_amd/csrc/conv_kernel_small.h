@@ -36,7 +36,10 @@ struct SmallK {
     int kh, kw, pad_h, pad_w, stride;
     int nch0, nch32;            // 32-channel chunks of src0 / of both sources
     int ntaps;
-    int tapslab[9];             // slab (first index of the fragment-order weights) of tap ky * kw + kx
+    unsigned long long tapslab; // 4 bits per tap ky * kw + kx: its slab (first index of the fragment-order weights).  Packed into a
+                                // scalar on purpose: a dynamically indexed ARRAY in the kernel arguments is read with vector loads
+                                // from the kernarg segment - host memory - at ~4 us per dependent load (measured: every launch
+                                // of the first version took 7.9 us against 3.7 us for a trivial kernel)
     const _Float16* wfrag;      // [slab][chunk][cout_pad/32][16-column half][hi|lo][64 lanes][8] halves
     int nt32;
     int nchw;                   // chunks per K range (gridDim.z ranges)
@@ -54,7 +57,8 @@ template <int PK>
 __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     const ConvK& p = sk.c;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_s[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: the step bookkeeping below stays on the SALU
     const int tile = blockIdx.x;
     const int mt = tile / p.NT, nt = tile - mt * p.NT;
     const int ks = blockIdx.z;
@@ -75,20 +79,24 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     const long wslab = (long)sk.nch32 * wchunk;                  // halves per slab (tap)
     struct BSet { h8 f[SMALL_NS][2][2]; };                       // [step][16-column half][hi, lo]
     BSet bw;
+    auto step_of = [&](int tt, int& cl, int& tap) __attribute__((always_inline)) {      // step -> (chunk, tap): chunk-major
+        cl = sdiv(tt, sk.m_taps);
+        tap = tt - cl * sk.ntaps;
+    };
     auto b_issue = [&](int step0) __attribute__((always_inline)) {
-        int tt = step0 + wave;                                   // (chunk, tap) of the wave's first step of this round
-        int cl = sdiv(tt, sk.m_taps), tap = tt - cl * sk.ntaps;
 #pragma unroll
         for (int i = 0; i < SMALL_NS; ++i) {
+            const int tt = step0 + wave + 4 * i;
             if (tt < nsteps) {
-                const _Float16* w = wbase + (long)sk.tapslab[tap] * wslab + (long)(cg0 + cl) * wchunk;
+                int cl, tap;
+                step_of(tt, cl, tap);
+                const int slab = (int)((sk.tapslab >> (4 * tap)) & 15ull);
+                const _Float16* w = wbase + (long)slab * wslab + (long)(cg0 + cl) * wchunk;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) bw.f[i][ct][hl] = *(const h8*)(w + (ct * 2 + hl) * 512);
             }
-            tt += 4; tap += 4;
-            while (tap >= sk.ntaps) { tap -= sk.ntaps; ++cl; }
         }
     };
     b_issue(0);
@@ -175,13 +183,34 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[f][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- the epilogue's operands (bias, weight scale, residuals of this thread's (row, 4 columns)) are fetched NOW, so that
+    // their round trip overlaps the contraction instead of following it
+    const int row = t >> 3, c4 = t & 7;
+    const int m = m0 + row, n = nt * 32 + c4 * 4;
+    const bool live = m < p.M && n < p.Cout && p.ksplit <= 1;
+    PixOff po, co;
+    po.d = po.r0 = po.r1 = 0;
+    co.d = co.r0 = co.r1 = 0;
+    f32x4 bs4 = {0.f, 0.f, 0.f, 0.f}, wsc = {1.f, 1.f, 1.f, 1.f}, rv0 = {0.f, 0.f, 0.f, 0.f}, rv1 = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        pix_offsets(p, 0, m, po);
+        chan_offsets(p, n, co);
+        if (p.vec_epi) {
+            bs4 = *(const f32x4*)(p.bias + n);
+            if (p.wscale) wsc = *(const f32x4*)(p.wscale + n);
+            if (p.res0) rv0 = *(const f32x4*)(p.res0 + po.r0 + co.r0);
+            if (p.res1) rv1 = *(const f32x4*)(p.res1 + po.r1 + co.r1);
+        }
+    }
+
     for (int step0 = 0; step0 < nsteps; step0 += 4 * SMALL_NS) {
         if (step0 > 0) b_issue(step0);                           // a later round of a long K range
-        int tt = step0 + wave;
-        int cl = sdiv(tt, sk.m_taps), tap = tt - cl * sk.ntaps;
 #pragma unroll
         for (int i = 0; i < SMALL_NS; ++i) {
+            const int tt = step0 + wave + 4 * i;
             if (tt < nsteps) {
+                int cl, tap;
+                step_of(tt, cl, tap);
                 const int ky = sk.kw == 1 ? tap : (tap * 11) >> 5, kx = tap - ky * sk.kw;       // tap / 3 for tap < 16
                 h8 ah[2], al[2];
 #pragma unroll
@@ -204,8 +233,6 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
                                 term == 2 ? al[f] : ah[f], term == 0 ? bw.f[i][ct][0] : term == 1 ? bw.f[i][ct][1] : bs[ct],
                                 acc[f][ct], 0, 0, 0);
             }
-            tt += 4; tap += 4;
-            while (tap >= sk.ntaps) { tap -= sk.ntaps; ++cl; }
         }
     }
     report_range(p, amax);
@@ -219,8 +246,6 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
             for (int r = 0; r < 4; ++r)
                 part[(wave * 32 + f * 16 + (lane >> 4) * 4 + r) * 32 + ct * 16 + (lane & 15)] = acc[f][ct][r];
     __syncthreads();
-    const int row = t >> 3, c4 = t & 7;
-    const int m = m0 + row, n = nt * 32 + c4 * 4;
     if (m >= p.M) return;
     f32x4 s = *(const f32x4*)(part + row * 32 + c4 * 4);
 #pragma unroll
@@ -230,18 +255,12 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
         return;
     }
     if (n >= p.Cout) return;
-    PixOff po, co;
-    pix_offsets(p, 0, m, po);
-    chan_offsets(p, n, co);
     if (p.vec_epi) {
-        const f32x4 bs4 = *(const f32x4*)(p.bias + n);
-        f32x4 wsc = {1.f, 1.f, 1.f, 1.f};
-        if (p.wscale) wsc = *(const f32x4*)(p.wscale + n);
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = act_apply(fmaf(s[c], wsc[c], bs4[c]), p.act);
-        if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
-        if (p.res1) v += *(const f32x4*)(p.res1 + po.r1 + co.r1);
+        if (p.res0) v += rv0;
+        if (p.res1) v += rv1;
         *(f32x4*)(p.dst + po.d + co.d) = v;
     } else {
 #pragma unroll

@@ -876,7 +876,7 @@ def test_small_image_kernel(B, c0, c1, cout, k, stride, H, W, pre, res, store, p
             assert ops.last_conv_kernel() != 8
         finally:
             del os.environ["FUSG_NO_SMALL"]
-        _close(got, old, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        _close(got, old.cpu(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
     assert tuple(got.shape) == tuple(ref.shape)
     _close(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
     assert not ops.range_exceeded(dev())

@@ -132,6 +132,8 @@ def _deferred(ops, fn):
 
 
 def measure(B=1):
+    import faulthandler
+    faulthandler.enable()
     torch, ops, pipe, batch, dev = _setup(B)
     from future_urban_scene_generation_amd import _lib as L
     out = {"batch": B}
