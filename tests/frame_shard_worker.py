@@ -19,8 +19,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# (max abs difference in uint8 levels, largest fraction of differing pixels) - sharded vs unsharded
-BARS = {"vunet_u8": (1, 2e-4), "icn_u8": (6, 2e-3), "frame_icn": (6, 2e-3), "frame_vunet": (2, 2e-4), "inpaint_u8": (1, 2e-4)}
+# (max abs difference in uint8 levels, largest fraction of differing pixels) - sharded vs unsharded.  Observed in round 4
+# (profiles/r04_parity.json, first / later frame): vunet_u8 1 level on 1.8e-5 / 1.6e-5 of the pixels, icn_u8 4 levels on 8.2e-5 /
+# 7.5e-5 (Lab -> BGR amplifies one Lab step), frame_icn 2 / 1 levels on 1.2e-5 / 7e-6, frame_vunet 1 level on 2.9e-6 / 1.4e-6
+BARS = {"vunet_u8": (1, 2e-4), "icn_u8": (8, 1e-3), "frame_icn": (6, 2e-4), "frame_vunet": (2, 5e-5), "inpaint_u8": (1, 2e-4)}
 
 
 def main():

@@ -797,7 +797,7 @@ def test_hg_bottleneck_fused_is_deterministic(precision):
             assert torch.equal(got, first), (planes, it)
 
 
-# ---- the small-image kernel (csrc/conv_kernel_small.h): images of <= 16 x 16 pixels -------------------------------
+# ---- the small-image kernel (csrc/conv_kernel_small.h): output images of <= 64 pixels -------------------------------
 SMALL = [  # B, c0, c1, cout, k, stride, H, W, pre_op, residual, store
     (32, 128, 0, 128, 3, 1, 8, 8, "elu", True, "normal"),        # VUnet Residual at 8 x 8: 32 rows = half an image
     (32, 128, 0, 128, 3, 1, 4, 4, "elu", True, "normal"),        # two whole images per workgroup
@@ -811,10 +811,9 @@ SMALL = [  # B, c0, c1, cout, k, stride, H, W, pre_op, residual, store
     (4, 128, 0, 128, 3, 2, 8, 8, "none", False, "normal"),       # 8 -> 4
     (4, 128, 0, 512, 3, 1, 4, 4, "none", False, "d2s"),          # UpSample('subpixel'): DepthToSpace store
     (4, 128, 0, 128, 3, 1, 8, 8, "elu", False, "s2d"),           # SpaceToDepth store
-    (4, 128, 0, 128, 3, 1, 16, 16, "elu", True, "normal"),       # 16 x 16: two image rows per workgroup
     (4, 256, 0, 128, 1, 1, 4, 4, "affine_relu", False, "normal"),   # hourglass Bottleneck conv1 (bn1 + ReLU on load)
     (4, 128, 0, 256, 1, 1, 4, 4, "relu", True, "normal"),        # hourglass Bottleneck conv3 + residual
-    (2, 128, 0, 128, 3, 1, 8, 16, "elu", True, "normal"),        # non-square: Wo = 16
+    (2, 128, 0, 128, 3, 1, 4, 16, "elu", True, "normal"),        # non-square: Wo = 16, two image rows per workgroup
 ]
 
 
@@ -866,10 +865,14 @@ def test_small_image_kernel(B, c0, c1, cout, k, stride, H, W, pre, res, store, p
         ref, kw["store"] = _d2s(ref), L.STORE_D2S
     elif store == "s2d":
         ref, kw["store"] = _s2d(ref), L.STORE_S2D
-    got = ops.conv(plan, a0, _nhwc(x1) if c1 else None, **kw)
+    import os
+    os.environ["FUSG_SMALL_KSPLIT"] = "1"          # K ranges over workgroups (+ slab reduce): off by default (measured slower), tested here
+    try:
+        got = ops.conv(plan, a0, _nhwc(x1) if c1 else None, **kw)
+    finally:
+        del os.environ["FUSG_SMALL_KSPLIT"]
     if precision == "f16x3":
         assert ops.last_conv_kernel() == 8, ops.last_conv_kernel()
-        import os
         os.environ["FUSG_NO_SMALL"] = "1"                          # the launches it replaces: generic gather (+ split-K reduce) / halo kernel
         try:
             old = ops.conv(plan, a0, _nhwc(x1) if c1 else None, **kw)
