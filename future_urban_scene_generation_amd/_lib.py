@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):            # fusg_conv_desc
                 ("wfrag_order", C.c_int32), ("wfrag", C.c_void_p), ("stats_out", C.c_void_p),
                 ("tile_list", C.c_void_p), ("tile_count", C.c_int32), ("q_oy", C.c_int32), ("q_ox", C.c_int32),
                 ("stats_slots", C.c_int32),
-                ("wscale", C.c_void_p), ("status", C.c_void_p), ("wfrag_bf16", C.c_void_p),
+                ("wscale", C.c_void_p), ("status", C.c_void_p), ("wfrag_bf16", C.c_void_p), ("wfrag_f32", C.c_void_p),
                 ("splitk_counters", C.c_void_p), ("splitk_counters_len", C.c_int32), ("_pad2", C.c_int32)]
 
 

@@ -5,11 +5,11 @@
 // 24.28 -> 23.54 ms, 1383 -> 1424 crops/s; the bf16 mode does not care (18.16 vs 18.19 ms).  -DFUSG_HALO_W22 builds 2 x 2.
 #include "conv_kernel_halo.h"
 namespace fusg {
-hipError_t launch_halo_128(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf16) {
+hipError_t launch_halo_128(const HaloK& k, dim3 grid, hipStream_t s, int pk, int mode) {
 #ifdef FUSG_HALO_W22
-    return launch_halo<2,2,2,2>(k, grid, s, pk, bf16);
+    return launch_halo<2,2,2,2>(k, grid, s, pk, mode);
 #else
-    return launch_halo<4,1,1,4>(k, grid, s, pk, bf16);
+    return launch_halo<4,1,1,4>(k, grid, s, pk, mode);
 #endif
 }
 }  // namespace fusg

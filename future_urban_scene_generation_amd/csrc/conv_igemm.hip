@@ -406,7 +406,9 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
     // halo kernel: stride 1 (any dilation / padding mode / fused upsample), or stride 2 in parity-quadrant form
     // (wfrag_order 1: k3/k4, pad 1, one source, even H and W); everything else takes the generic gather
     const bool s2d_form = d->wfrag_order == 1 && d->stride == 2 && x0.h % 2 == 0 && x0.w % 2 == 0;
-    const bool halo_ok = d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->ksplit <= 1 &&
+    const bool f32_halo = d->precision == FUSG_PREC_F32 && d->wfrag_f32 != nullptr && (((uintptr_t)d->wfrag_f32) & 15) == 0 &&
+                          getenv("FUSG_NO_F32_HALO") == nullptr;
+    const bool halo_ok = (d->precision == FUSG_PREC_F16X3 || f32_halo) && nphase == 1 && d->ksplit <= 1 &&
                          ((d->stride == 1 && d->wfrag_order == 0) || (s2d_form && d->upsample == 0)) &&
                          d->kh >= 1 && d->kw >= 1 && d->dil >= 1 && d->c0k % 32 == 0 && d->c0k > 0 &&
                          (!has1 || (d->k_pad / (d->kh * d->kw) - d->c0k) % 32 == 0) && d->qh % 8 == 0 && d->qw % 16 == 0 &&
@@ -580,6 +582,8 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
             const bool bf = want_bf16 && d->wfrag_bf16 != nullptr && (((uintptr_t)d->wfrag_bf16) & 15) == 0;
             if (bf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
+            if (f32_halo) { h.wfrag = (const _Float16*)d->wfrag_f32; h.c.wscale = nullptr; h.c.status = nullptr; }
+            const int mode = f32_halo ? 2 : (bf ? 1 : 0);
             // narrow column tiles of k x k layers on SMALL grids: K split over the waves (conv_kernel_halo.h, KS) when every wave
             // gets a tap.  Measured per dispatch inside the pass (round 3, same card): grids of 256 - 1024 workgroups 2 - 14 %
             // shorter (their time is one workgroup's latency); grids of 4096 - 16384 workgroups 19 - 42 % LONGER (the four
@@ -588,11 +592,11 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             const int ntaps = d->kh * d->kw;
             const bool ks_ok = !s2d_form && !d->tile_list && !env_switches().no_ksplit && (long)h.c.MT * h.c.NT <= 1024;
             const bool k4 = ks_ok && bn == 32 && ntaps >= 4, k2 = ks_ok && bn == 64 && ntaps >= 2;
-            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk, bf)
-                          : bn == 64 ? (k2 ? launch_halo_64k(h, hgrid, s, pk, bf) : launch_halo_64(h, hgrid, s, pk, bf))
-                                     : (k4 ? launch_halo_32k(h, hgrid, s, pk, bf) : launch_halo_32(h, hgrid, s, pk, bf));
+            e = bn == 128 ? launch_halo_128(h, hgrid, s, pk, mode)
+                          : bn == 64 ? (k2 ? launch_halo_64k(h, hgrid, s, pk, mode) : launch_halo_64(h, hgrid, s, pk, mode))
+                                     : (k4 ? launch_halo_32k(h, hgrid, s, pk, mode) : launch_halo_32(h, hgrid, s, pk, mode));
             if (e != hipSuccess) { set_error("conv2d halo launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
-            note_conv_kernel(bf ? FUSG_CONV_HALO_BF16 : (h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO));
+            note_conv_kernel(f32_halo ? FUSG_CONV_HALO_F32 : bf ? FUSG_CONV_HALO_BF16 : (h.s2d ? FUSG_CONV_HALO_S2D : FUSG_CONV_HALO));
             prof_end(0, s);
             return FUSG_OK;
         }

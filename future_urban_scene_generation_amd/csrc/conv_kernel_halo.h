@@ -43,6 +43,15 @@ namespace fusg {
 // half the operand traffic; ~2^-9 relative error per operand - measured on the networks' fixtures: SSIM >= 0.9997 on
 // every image output, NOT bit-exact on the hourglass's keypoint argmax, which therefore stays on f16x3
 // (tests::test_reduced_precision_evidence, profiles/r02_parity.json).
+// MODE 2 (FUSG_PREC_F32, the reference's own arithmetic and the range guard's fallback): the same kernel on the fp32 matrix
+// instruction v_mfma_f32_16x16x4_f32 (an exact fp32 fmaf chain, 64 FLOP / clk / SIMD = the fp32 vector peak): the halo image
+// holds the pre-processed activations as fp32 (128 bytes per pixel and chunk: the bytes of the (hi, lo) pair), a lane's A
+// operand of the 8 instructions of a 32-channel chunk is two 16-byte reads (channels 4g .. 4g+3 and 16 + 4g .. of its pixel,
+// g = lane >> 4; instruction (h, e) contracts channels {16h + 4g + e}), and the weights come from a third fragment-order
+// copy [tap][chunk32][cout_pad/32][16-column half][h][64 lanes][4 floats] (pack.py: frag_f32) - again one contiguous 1 KiB
+// wave load per fragment, the same 4 KiB per 32-column tile and step as the split-fp16 mode.  The matrix pipe is 16x slower
+// per FLOP than in fp16, so neither LDS nor the weight stream matters here (16 KiB of reads per 4096 MFMA cycles and wave).
+// K runs chunk-major here and tap-major in the generic fp32 kernel: the two agree to fp32 rounding, not bit for bit.
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
@@ -105,7 +114,7 @@ constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
 // weight fragments, and the per-step overhead is paid a quarter as often.  It pays on small grids only (conv_igemm.hip).
 template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE, int KS = 1>
 __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
-    constexpr bool BF = MODE == 1;
+    constexpr bool BF = MODE == 1, F32 = MODE == 2;
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
     constexpr int LOGC = 3;
@@ -119,6 +128,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     const int HP = hk.HH * hk.HW;
     _Float16* Ah = smem_h;                         // [HH][RP]: rows of HW pixels x HPITCH halves (+ row padding)
     _Float16* Al = Ah + hk.HH * hk.RP;
+    float* Af = (float*)smem_h;                    // MODE 2: [HH][HW] pixels x 32 fp32 (the same bytes as the two fp16 images)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -155,7 +165,8 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         if (pix < HP) {
             hexist |= 1u << j;
             const int hy = fdiv(pix, hk.m_hw), hx = pix - hy * hk.HW;
-            hoff[j] = hy * hk.RP + hx * HPITCH + ((((kc >> 1) ^ (((hx >> 2) & 1) << 1)) << 3) | ((kc & 1) << 2));
+            hoff[j] = F32 ? hy * hk.RP + hx * 32 + ((kc ^ ((hx >> 1) & 7)) << 2)         // floats; 16-byte slot kc swizzled by the column
+                          : hy * hk.RP + hx * HPITCH + ((((kc >> 1) ^ (((hx >> 2) & 1) << 1)) << 3) | ((kc & 1) << 2));
             int vy = oy0 - hk.pad_h + hy, vx = ox0 - hk.pad_w + hx;
             bool ok = true;
             if (hk.s2d) {
@@ -250,7 +261,11 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], S.sc[c], S.sh[c]); v[c] = ok ? y : 0.f; }
             }
-            if constexpr (BF) {
+            if constexpr (F32) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], vfloor);
+                if ((hexist >> j) & 1u) *(f32x4*)(Af + hoff[j]) = v;
+            } else if constexpr (BF) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], vfloor);
                 const bf4 hb = __builtin_convertvector(v, bf4);
@@ -290,7 +305,30 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     auto compute = [&](int dyp, int dxp, const BFrag& F) __attribute__((always_inline)) {          // (dyp, dxp): halo pixel offset of the tap
         const int hx = (lane & 15) + dxp;
         const int toff = dyp * hk.RP + hx * HPITCH + (((lane >> 4) ^ (((hx >> 2) & 1) << 1)) << 3);
-        if constexpr (BF) {
+        if constexpr (F32) {
+            const int sw = (hx >> 1) & 7, g = lane >> 4;
+            const int tf = dyp * hk.RP + hx * 32;
+            f32x4 a0[2 * TM], a1[2 * TM];
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                a0[i] = *(const f32x4*)(Af + abase[i] + tf + ((g ^ sw) << 2));
+                a1[i] = *(const f32x4*)(Af + abase[i] + tf + (((g + 4) ^ sw) << 2));
+            }
+            // instruction-major order: consecutive MFMAs write different accumulators (40-cycle dependent latency)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                const f32x4 bv = __builtin_bit_cast(f32x4, F.f[j][ct][h]);
+                                acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h ? a1[i][e] : a0[i][e], bv[e], acc[i][2 * j + ct], 0, 0, 0);
+                            }
+        } else if constexpr (BF) {
             bf8 ab[2 * TM];
 #pragma unroll
             for (int i = 0; i < 2 * TM; ++i) ab[i] = *(const bf8*)(Ah + abase[i] + toff);
@@ -450,7 +488,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
 
     }
 
-    if constexpr (!BF) report_range(p, amax);
+    if constexpr (!BF && !F32) report_range(p, amax);
     if constexpr (KS > 1) {
         // ---- K split: partial tiles -> LDS ([wave][128 rows][32 columns] fp32, over the halo images), summed in wave order by
         // the wave that finishes those rows: wave (wk, wn) takes rows 128 / KS * wk ... of column tile wn
@@ -543,7 +581,7 @@ inline size_t halo_lds_bytes(int HH, int HW) { return (size_t)2 * HH * halo_row_
 inline bool halo_fits(int HH, int HW) { return HH * HW * 8 <= 2560 && halo_lds_bytes(HH, HW) <= 96 * 1024; }
 
 template <int TM, int TN, int WM, int WN, int KS = 1>
-hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf16) {
+hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, int mode) {      // mode: 0 split-fp16, 1 bf16, 2 exact fp32
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour (K split: the four partial tiles)
@@ -556,7 +594,9 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
     if (ni <= 6) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 6, MD, KS>;                  \
     else if (ni <= 8) fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 8, MD, KS>;             \
     else fn = (const void*)conv_halo_h3<TM, TN, WM, WN, PKV, 10, MD, KS>;
-    if (bf16) {
+    if (mode == 2) {
+        if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 2) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 2) } else { FUSG_PICK_NI(PK_AFFINE, 2) }
+    } else if (mode == 1) {
         if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 1) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 1) } else { FUSG_PICK_NI(PK_AFFINE, 1) }
     } else {
         if (pk == PK_NONE) { FUSG_PICK_NI(PK_NONE, 0) } else if (pk == PK_ELU) { FUSG_PICK_NI(PK_ELU, 0) } else { FUSG_PICK_NI(PK_AFFINE, 0) }
@@ -581,10 +621,10 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, bool bf
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
 
-hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int, bool);
-hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int, bool);
-hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int, bool);
-hipError_t launch_halo_32k(const HaloK&, dim3, hipStream_t, int, bool);     // K split over the four waves
-hipError_t launch_halo_64k(const HaloK&, dim3, hipStream_t, int, bool);     // K split over two waves per 32-column tile
+hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int, int);
+hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int, int);
+hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int, int);
+hipError_t launch_halo_32k(const HaloK&, dim3, hipStream_t, int, int);      // K split over the four waves
+hipError_t launch_halo_64k(const HaloK&, dim3, hipStream_t, int, int);      // K split over two waves per 32-column tile
 
 }  // namespace fusg

@@ -94,8 +94,8 @@ def range_guarded() -> bool:
 
 
 def halo_precision() -> bool:
-    """Does the current precision route qualifying layers to the halo kernel?"""
-    return PRECISION in ("f16x3", "bf16")
+    """Does the current precision route qualifying layers to the halo kernel?  (f32: its exact-fp32 mode, round 4.)"""
+    return PRECISION in ("f16x3", "bf16") or (PRECISION == "f32" and not _env_set("FUSG_NO_F32_HALO"))
 
 
 def new_status_word(device) -> torch.Tensor:
@@ -468,6 +468,12 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
             d.wfrag_order = dev["wfrag_order"]
             if prec_name == "bf16" and dev.get("wfrag_bf16") is not None:
                 d.wfrag_bf16 = dev["wfrag_bf16"].data_ptr()
+            if prec_name == "f32" and dev["wfrag_order"] in (0, 1) and not _env_set("FUSG_NO_F32_HALO"):
+                ff = plan.frag_f32_dev()                  # exact-fp32 halo kernel (built on first use)
+                if ff is not None:
+                    d.wfrag_f32 = ff.data_ptr()
+                    if RECORDER is not None:
+                        RECORDER.keep.append(ff)
     lib = L.lib()
     nbytes = lib.fusg_conv2d_plan(C.byref(d))
     ws = None
@@ -593,8 +599,8 @@ def conv_up2(exact: ConvPlan, phases, x: torch.Tensor, *, pre_op: int = L.PRE_NO
     b, c, h, w = x.shape
     out = nhwc_empty(b, exact.cout, 2 * h, 2 * w, x.device)
     # split-K launches do not use the halo kernel: keep K whole where the phase launches qualify for it
-    halo = ((precision or PRECISION) in ("f16x3", "bf16") and c % 32 == 0 and h % 8 == 0 and w % 16 == 0
-            and _os.environ.get("FUSG_NO_HALO") is None)
+    halo = (((precision or PRECISION) in ("f16x3", "bf16") or ((precision or PRECISION) == "f32" and not _env_set("FUSG_NO_F32_HALO")))
+            and c % 32 == 0 and h % 8 == 0 and w % 16 == 0 and _os.environ.get("FUSG_NO_HALO") is None)
     if isinstance(phases, ConvPlan):                               # all four phases in one launch, DepthToSpace store
         conv(phases, x, out=out, store=L.STORE_D2S, pre_op=pre_op, pre=pre, pre_bstride=pre_bstride,
              precision=precision, ksplit=1 if halo else 0)

@@ -72,6 +72,16 @@ class ConvPlan:
             self.dev["wfrag_order"] = 1 if self.s2d_ok() else (2 if self.tapunit_ok() else 0)   # fusg_conv_desc.wfrag_order
         return self
 
+    def frag_f32_dev(self):
+        """fusg_conv_desc.wfrag_f32 (exact-fp32 halo kernel), built and uploaded on first use: only `precision="f32"` passes
+        and the range guard's fallback need it.  None when the layer cannot use the halo kernel."""
+        if "wfrag_f32" not in self.dev:
+            ff = frag_f32(self.wpack, self) if (self.nphase == 1 and self.dev.get("wfrag") is not None and self.dev["wfrag_order"] in (0, 1)) else None
+            if ff is not None and self.s2d_ok():
+                ff = ff[s2d_tap_order(self.kh)].contiguous()
+            self.dev["wfrag_f32"] = None if ff is None else ff.to(self.dev["wpack"].device).contiguous()
+        return self.dev["wfrag_f32"]
+
     def s2d_ok(self) -> bool:
         """Stride-2 k3/k4 pad-1 layer whose halo-kernel weights are stored in parity-quadrant order
         (fusg_conv_desc.wfrag_order = 1, see s2d_tap_order)."""
@@ -150,6 +160,22 @@ def frag_bf16(wpack: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:
     w = w.view(nt32, 2, 16, taps, nch, 4, 8)                    # nt, ct, r, tap, chunk, g, j
     w = w.permute(3, 4, 0, 1, 5, 2, 6)                          # tap, chunk, nt, ct, g, r, j
     return w.reshape(taps, nch, nt32, 2, 64, 8).contiguous()
+
+
+def frag_f32(wpack: torch.Tensor, plan: "ConvPlan") -> Optional[torch.Tensor]:
+    """The fp32 weights in the halo kernel's fragment order for v_mfma_f32_16x16x4_f32 (fusg_conv_desc.wfrag_f32):
+    [tap][chunk32][cout_pad/32][16-column half][h][lane 64][4 floats], lane = g * 16 + column holding
+    w[column][32 chunk + 16 h + 4 g + e], e = 0..3 - what lane (column, g) feeds the instruction (h, e) of a chunk as B.
+    None when the layer cannot use the halo kernel."""
+    taps = plan.kh * plan.kw
+    ctot = plan.c0k + plan.c1k
+    if plan.nphase != 1 or taps < 1 or plan.c0k % 32 or plan.c1k % 32 or ctot == 0 or plan.k_pad != taps * ctot:
+        return None
+    w = wpack[0]                                                # [cout_pad, k_pad]
+    nt32, nch = plan.cout_pad // 32, ctot // 32
+    w = w.view(nt32, 2, 16, taps, nch, 2, 4, 4)                 # nt, ct, r, tap, chunk, h, g, e
+    w = w.permute(3, 4, 0, 1, 5, 6, 2, 7)                       # tap, chunk, nt, ct, h, g, r, e
+    return w.reshape(taps, nch, nt32, 2, 2, 64, 4).contiguous()
 
 
 def s2d_quadrant_taps(k: int):

@@ -906,3 +906,59 @@ def test_small_image_kernel_range_guard_and_determinism(precision):
     x[3, 17, 2, 1] = 7.0e4                                        # outside the split's range: the status word, not a clamp
     ops.conv(plan, _nhwc(x))
     assert ops.range_exceeded(dev())
+
+
+# ---- exact-fp32 mode of the halo kernel (csrc/conv_kernel_halo.h MODE 2, fusg_conv_desc.wfrag_f32) -------------------------
+F32_HALO = [  # B, c0, c1, cout, k, stride, pad, dil, pad_mode, H, W, pre
+    (2, 128, 0, 128, 3, 1, 1, 1, 0, 64, 64, "elu"),       # VUnet residual
+    (1, 256, 0, 256, 3, 1, 2, 2, 1, 32, 32, "affine_relu"),   # EdgeConnect dilated block, reflect, IN-on-load
+    (2, 64, 0, 128, 4, 2, 1, 1, 1, 32, 64, "none"),       # stride 2 in parity-quadrant form
+    (1, 128, 0, 64, 5, 1, 2, 1, 1, 16, 32, "none"),       # 5 x 5
+    (2, 32, 64, 32, 3, 1, 1, 1, 0, 16, 32, "elu"),        # two sources, 32-column tile (K split over the waves on this small grid)
+    (2, 256, 0, 128, 1, 1, 0, 1, 0, 32, 32, "relu"),      # 1 x 1
+]
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,k,stride,pad,dil,pm,H,W,pre", F32_HALO)
+def test_f32_halo_kernel(B, c0, c1, cout, k, stride, pad, dil, pm, H, W, pre, precision):
+    """precision="f32" on a halo-eligible layer runs v_mfma_f32_16x16x4_f32 from a staged halo (kernel family 9) and agrees
+    with the generic fp32 gather it replaces (FUSG_NO_F32_HALO=1) to fp32 rounding - K runs chunk-major here, tap-major there,
+    so not bit for bit - and is as close to an fp64 reference as that kernel is."""
+    if precision != "f32":
+        pytest.skip("f32 only")
+    import os
+    cin = c0 + c1
+    x0 = _rand(B, c0, H, W, seed=1)
+    x1 = _rand(B, c1, H, W, seed=2) if c1 else None
+    w = _rand(cout, cin, k, k, seed=3, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=4)
+    plan = pack.pack_conv(w, b, c_split=(c0, c1) if c1 else None, stride=stride, pad=pad, dil=dil, pad_mode=pm)
+    xc = torch.cat([x0, x1], 1) if c1 else x0
+    kw = {}
+    if pre == "elu":
+        xin, kw["pre_op"] = F.elu(xc), L.PRE_ELU
+    elif pre == "relu":
+        xin, kw["pre_op"] = F.relu(xc), L.PRE_RELU
+    elif pre == "affine_relu":
+        sc, sh = _rand(B, cin, seed=5), _rand(B, cin, seed=6)
+        xin = F.relu(xc * sc.view(B, cin, 1, 1) + sh.view(B, cin, 1, 1))
+        kw.update(pre_op=L.PRE_AFFINE_RELU, pre=(sc.to(dev()), sh.to(dev())), pre_bstride=cin)
+    else:
+        xin = xc
+    xp = F.pad(xin.double(), (pad,) * 4, mode="reflect") if pm else xin.double()
+    ref = F.conv2d(xp, w.double(), b.double(), stride=stride, padding=0 if pm else pad, dilation=dil)
+    a0, a1 = _nhwc(x0), (_nhwc(x1) if c1 else None)
+    got = ops.conv(plan, a0, a1, **kw)
+    assert ops.last_conv_kernel() == 9, ops.last_conv_kernel()
+    os.environ["FUSG_NO_F32_HALO"] = "1"
+    try:
+        old = ops.conv(plan, a0, a1, **kw)
+        assert ops.last_conv_kernel() == 0
+    finally:
+        del os.environ["FUSG_NO_F32_HALO"]
+    scale = float(ref.abs().max())
+    e_new = float((got.cpu().double() - ref).abs().max()) / scale
+    e_old = float((old.cpu().double() - ref).abs().max()) / scale
+    assert e_new <= max(2 * e_old, 5e-7), (e_new, e_old)
+    _close(got, old.cpu(), rtol=1e-5, atol=2e-6 * scale)
+    assert torch.equal(got, ops.conv(plan, a0, a1, **kw))          # deterministic
