@@ -461,9 +461,10 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             }
         }
     }
-    // pointwise from <= 8 channels: the streaming VALU kernel above (split-fp16 precision only: the exact-fp32 path keeps
-    // its one kernel family; the result is the fp32 kernel's, bit for bit)
-    if (d->precision == FUSG_PREC_F16X3 && nphase == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->upsample == 0 && !has1 &&
+    // pointwise from <= 8 channels: the streaming VALU kernel above - an exact fp32 fmaf chain in the generic fp32 kernel's k
+    // order, so it serves both the split-fp16 and (round 4) the exact-fp32 precision with that kernel's bits
+    // (FUSG_NO_POINTWISE, read per call, keeps the MFMA kernels: tests compare the two)
+    if ((d->precision == FUSG_PREC_F16X3 || d->precision == FUSG_PREC_F32) && getenv("FUSG_NO_POINTWISE") == nullptr && nphase == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->upsample == 0 && !has1 &&
         d->c0k >= 4 && d->c0k <= 8 && d->ksplit <= 1 && d->store_mode == FUSG_STORE_NORMAL && k.vec_epi && !d->stats_out &&
         d->cout % 4 == 0 && d->pre_op <= FUSG_PRE_ELU && (d->q_oy | d->q_ox) == 0 && !d->tile_list && d->wpack && d->pad_h == 0 &&
         d->pad_w == 0 && 256 % (d->cout_pad >> 2) == 0 && !env_switches().no_halo && !env_switches().no_pointwise) {
@@ -584,6 +585,25 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             if (bf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
             if (f32_halo) { h.wfrag = (const _Float16*)d->wfrag_f32; h.c.wscale = nullptr; h.c.status = nullptr; }
             const int mode = f32_halo ? 2 : (bf ? 1 : 0);
+            // bf16 mode on a 16 x 16 pixel patch (conv_kernel_halo.h, BM == 256; FUSG_BF16_BIG=14|22 picks the wave layout, 0 = off)
+            if (bf && bn == 128 && !s2d_form && !d->tile_list && d->qh % 16 == 0 && d->qw % 16 == 0) {
+                static const int big = [] { const char* v = getenv("FUSG_BF16_BIG"); return v ? atoi(v) : 14; }();
+                const int HHb = 15 + (d->kh - 1) * d->dil + 1;
+                if (big != 0 && HHb * h.HW * 8 <= 256 * 12) {
+                    HaloK hb = h;
+                    hb.HH = HHb;
+                    hb.tiles_per_img = (d->qh / 16) * hb.tiles_x;
+                    hb.c.MT = (int)x0.n * hb.tiles_per_img;
+                    dim3 bgrid(hb.c.MT * hb.c.NT, 1, 1);
+                    e = big == 22 ? launch_halo_big22(hb, bgrid, s, pk) : launch_halo_big14(hb, bgrid, s, pk);
+                    if (e == hipSuccess) {
+                        note_conv_kernel(FUSG_CONV_HALO_BF16);
+                        prof_end(0, s);
+                        return FUSG_OK;
+                    }
+                    (void)hipGetLastError();                     // does not fit: the 8 x 16 patch below
+                }
+            }
             // narrow column tiles of k x k layers on SMALL grids: K split over the waves (conv_kernel_halo.h, KS) when every wave
             // gets a tap.  Measured per dispatch inside the pass (round 3, same card): grids of 256 - 1024 workgroups 2 - 14 %
             // shorter (their time is one workgroup's latency); grids of 4096 - 16384 workgroups 19 - 42 % LONGER (the four

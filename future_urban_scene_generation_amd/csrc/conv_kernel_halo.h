@@ -29,6 +29,7 @@
 // Loop nest: source -> 32-channel chunk -> tap;  K index of a (chunk, tap) weight tile in the packed
 // panel = tap * Ctot + channel (same panels as the generic kernel, no re-packing).
 #pragma once
+#include <type_traits>
 #include "conv_kernel_h3.h"
 #ifndef FUSG_HALO_WAVES
 #define FUSG_HALO_WAVES 2
@@ -113,7 +114,7 @@ constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
 // (profiles/r03_pmc_narrow_layers.txt); here a step is 48 MFMAs like on the 128-column tile, every wave fetches different
 // weight fragments, and the per-step overhead is paid a quarter as often.  It pays on small grids only (conv_igemm.hip).
 template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE, int KS = 1>
-__global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
+__global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
     constexpr bool BF = MODE == 1, F32 = MODE == 2;
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
     constexpr int BM = 32 * TM * WM;               // 128 output pixels = 8 rows x 16 columns
     constexpr int BN = 32 * TN * WN;
     constexpr int PR = BM / 16;                    // patch rows
-    static_assert(BM == 128 && WM * WN * KS == 4, "8x16 pixel patch, 4 waves");
+    // BM == 256 ("big patch", bf16 mode only, launch_halo_big): a 16 x 16 pixel patch per workgroup - twice the MFMAs per weight
+    // fragment fetched and per step of bookkeeping, a halo of 1.27x instead of 1.41x the patch
+    static_assert((BM == 128 || (BM == 256 && MODE == 1 && KS == 1)) && WM * WN * KS == 4, "8x16 (or 16x16) pixel patch, 4 waves");
     static_assert(KS == 1 || (WM == 1 && TN == 1 && TM == 4), "K split: every wave owns the whole patch and one 32-column tile");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int HP = hk.HH * hk.HW;
@@ -547,6 +550,29 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         return p.stats + ((long)b * p.stats_slots + t2 * (BM / 32) + ((wm * TM * 32) >> 5) + i) * p.Cout * 2;
     };
     if (p.vec_epi) {
+        if constexpr (BM == 256) {
+            // the wave's tile (TM * 32 rows) leaves in two halves through a wave-private LDS region of half the size (64 KiB per
+            // workgroup instead of 128: two workgroups still share a CU); residuals are read in the pass, not prefetched
+            // (the prefetch set would be 128 more registers)
+            constexpr int TH = TM / 2;
+            __syncthreads();
+            float* wlds = (float*)smem_h + wave * (TH * 32 * TN * 32);
+            ResRegs<TH, TN> none;
+            auto do_half = [&](auto halfc) __attribute__((always_inline)) {
+                constexpr int half = decltype(halfc)::value;           // compile-time: the accumulators stay in registers
+                f32x4 sub[2 * TH][2 * TN];
+#pragma unroll
+                for (int i = 0; i < 2 * TH; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; ++j) sub[i][j] = acc[half * 2 * TH + i][j];
+                auto pixh = [&](int row, PixOff& po) { return pixfn(half * TH * 32 + row, po); };
+                auto stath = [&](int i) -> float* { return statfn(half * TH + i); };
+                epilogue_vec16<TH, TN>(p, wlds, sub, lane, nt * BN + wn * TN * 32, pixh, stath, none, false);
+            };
+            do_half(std::integral_constant<int, 0>{});
+            do_half(std::integral_constant<int, 1>{});
+            return;
+        } else {
         ResRegs<TM, TN> rr;
         const bool pre = p.res0 != nullptr;
         if (pre) res_prefetch<TM, TN>(p, lane, nt * BN + wn * TN * 32, pixfn, rr);     // in flight across the barrier and the LDS detour
@@ -554,6 +580,7 @@ __global__ __launch_bounds__(256, halo_waves(TM, TN)) void conv_halo_h3(const Ha
         float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
         epilogue_vec16<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn, rr, pre);
         return;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2 * TN; ++j) {                     // C/D map of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -621,7 +648,42 @@ hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, int mod
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
 
+// bf16 mode, 16 x 16 pixel patch x 128 columns (BM == 256): the host sets HH / tiles_per_img for 16 patch rows
+template <int TM, int TN, int WM, int WN>
+hipError_t launch_halo_big(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
+    static_assert(32 * TM * WM == 256, "16 x 16 pixel patch");
+    const int HP = k.HH * k.HW;
+    size_t lds = (size_t)k.HH * halo_row_pitch(k.HW) * sizeof(_Float16);                        // ONE (bf16) halo image
+    constexpr size_t EPI = (size_t)4 * (TM / 2) * 32 * TN * 32 * sizeof(float);
+    if (lds < EPI) lds = EPI;
+    const int touch_off = (int)lds;
+    lds += TOUCH_LDS_BYTES;
+    if (HP * 8 > 256 * 12 || lds > 80 * 1024) return hipErrorInvalidValue;
+    const void* fn = pk == PK_NONE ? (const void*)conv_halo_h3<TM, TN, WM, WN, PK_NONE, 12, 1, 1>
+                   : pk == PK_ELU  ? (const void*)conv_halo_h3<TM, TN, WM, WN, PK_ELU, 12, 1, 1>
+                                   : (const void*)conv_halo_h3<TM, TN, WM, WN, PK_AFFINE, 12, 1, 1>;
+    if (hipError_t e = ensure_dyn_lds(fn, 80 * 1024 + TOUCH_LDS_BYTES); e != hipSuccess) return e;
+    HaloK kk = k;
+    kk.RP = halo_row_pitch(k.HW);
+    kk.touch_off = touch_off;
+    bool fits = true;
+    auto magic = [&fits](long nmax, int d) -> unsigned {
+        if (d < 1 || nmax * d >= (1L << 32)) fits = false;
+        return d < 2 ? 0u : (unsigned)(((1UL << 32) + (unsigned long)d - 1) / (unsigned long)d);
+    };
+    const long ntiles = (long)grid.x;
+    kk.m_hw = magic(256L * 12 + 255, k.HW);
+    kk.m_nt = magic(ntiles, k.c.NT);
+    kk.m_tpi = magic(ntiles, k.tiles_per_img);
+    kk.m_tx = magic((long)k.tiles_per_img, k.tiles_x);
+    if (!fits) return hipErrorInvalidValue;
+    void* args[] = {(void*)&kk};
+    return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
+}
+
 hipError_t launch_halo_128(const HaloK&, dim3, hipStream_t, int, int);
+hipError_t launch_halo_big22(const HaloK&, dim3, hipStream_t, int);        // 16 x 16 patch, waves 2 x 2 (128 pixels x 64 columns each)
+hipError_t launch_halo_big14(const HaloK&, dim3, hipStream_t, int);        // 16 x 16 patch, waves 1 x 4 (256 pixels x 32 columns each)
 hipError_t launch_halo_64(const HaloK&, dim3, hipStream_t, int, int);
 hipError_t launch_halo_32(const HaloK&, dim3, hipStream_t, int, int);
 hipError_t launch_halo_32k(const HaloK&, dim3, hipStream_t, int, int);      // K split over the four waves

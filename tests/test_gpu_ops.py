@@ -172,7 +172,7 @@ def test_conv_stride2_quadrant_form(cin, cout, k, pm, H, W, precision):
     xin = F.pad(x, (1,) * 4, mode="reflect") if pm else F.pad(x, (1,) * 4)
     ref = F.conv2d(xin, w, b, stride=2)
     got = ops.conv(plan, _nhwc(x), ksplit=1, pre_op=L.PRE_NONE)
-    assert ops.last_conv_kernel() == (3 if precision == "f16x3" else 0)
+    assert ops.last_conv_kernel() == (3 if precision == "f16x3" else 9)           # (f32: the halo kernel's exact-fp32 mode, round 4)
     _close(got, ref)
     # ELU pre-op + residual through the same path (VUnet DownSample sees ELU'd inputs elsewhere; covers the pre-op kinds)
     got = ops.conv(plan, _nhwc(x), ksplit=1, pre_op=L.PRE_ELU)
@@ -281,8 +281,8 @@ def test_conv_transpose_phases(cin, cout, H, W, precision):
     phases = pack.pack_conv_transpose_k4s2p1_phases(w, b)
     out, stats = ops.conv_transpose_phases(phases, _nhwc(x), want_stats=True)
     _close(out, ref)
-    halo = precision == "f16x3" and H % 8 == 0 and W % 16 == 0
-    assert ops.last_conv_kernel() == (2 if halo else (1 if precision == "f16x3" else 0))
+    halo = H % 8 == 0 and W % 16 == 0
+    assert ops.last_conv_kernel() == ((2 if precision == "f16x3" else 9) if halo else (1 if precision == "f16x3" else 0))
     out2, (sc, sh) = ops.conv_in(phases, _nhwc(x))
     _close(out2, ref)
     mean, var = ref.mean(dim=(2, 3)), ref.var(dim=(2, 3), unbiased=False)
@@ -417,7 +417,13 @@ def test_pointwise_from_few_channels(cin, cout, pre, precision):
     rin = _nhwc(res)
     got = ops.conv(plan, xin, pre_op=pre, res0=rin, act=L.ACT_TANH, precision="f16x3")
     fam = ops.last_conv_kernel()
-    want32 = ops.conv(plan, xin, pre_op=pre, res0=rin, act=L.ACT_TANH, precision="f32")
+    import os
+    os.environ["FUSG_NO_POINTWISE"] = "1"                       # the exact-fp32 MFMA kernel itself (f32 takes the streaming kernel too)
+    try:
+        want32 = ops.conv(plan, xin, pre_op=pre, res0=rin, act=L.ACT_TANH, precision="f32")
+        assert ops.last_conv_kernel() == 0
+    finally:
+        del os.environ["FUSG_NO_POINTWISE"]
     xp = {L.PRE_NONE: x, L.PRE_RELU: F.relu(x), L.PRE_ELU: F.elu(x)}[pre]
     ref = torch.tanh(F.conv2d(xp, w, b)) + res
     _close(got, ref)
