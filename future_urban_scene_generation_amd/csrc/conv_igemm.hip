@@ -585,9 +585,11 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             if (bf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
             if (f32_halo) { h.wfrag = (const _Float16*)d->wfrag_f32; h.c.wscale = nullptr; h.c.status = nullptr; }
             const int mode = f32_halo ? 2 : (bf ? 1 : 0);
-            // bf16 mode on a 16 x 16 pixel patch (conv_kernel_halo.h, BM == 256; FUSG_BF16_BIG=14|22 picks the wave layout, 0 = off)
+            // bf16 mode on a 16 x 16 pixel patch (conv_kernel_halo.h, BM == 256; FUSG_BF16_BIG=14|22 picks the wave layout).  OFF by
+            // default: measured 1.4x (1 x 4 waves) and 3x (2 x 2) SLOWER than the 8 x 16 patch (profiles/r04_ab_experiments.txt) - 128
+            // accumulator registers per wave leave one wave per SIMD, and nothing then overlaps the fp32 -> bf16 staging
             if (bf && bn == 128 && !s2d_form && !d->tile_list && d->qh % 16 == 0 && d->qw % 16 == 0) {
-                static const int big = [] { const char* v = getenv("FUSG_BF16_BIG"); return v ? atoi(v) : 14; }();
+                static const int big = [] { const char* v = getenv("FUSG_BF16_BIG"); return v ? atoi(v) : 0; }();
                 const int HHb = 15 + (d->kh - 1) * d->dil + 1;
                 if (big != 0 && HHb * h.HW * 8 <= 256 * 12) {
                     HaloK hb = h;

@@ -265,12 +265,17 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], S.sc[c], S.sh[c]); v[c] = ok ? y : 0.f; }
             }
             if constexpr (F32) {
+                // (only a fused ReLU clamps: fmaxf(NaN, -inf) would turn a NaN into -inf, and a NaN must reach the output)
+                if (vfloor == 0.f) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], vfloor);
+                    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], 0.f);
+                }
                 if ((hexist >> j) & 1u) *(f32x4*)(Af + hoff[j]) = v;
             } else if constexpr (BF) {
+                if (vfloor == 0.f) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], vfloor);
+                    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], 0.f);
+                }
                 const bf4 hb = __builtin_convertvector(v, bf4);
                 if ((hexist >> j) & 1u) *(bf4*)(Ah + hoff[j]) = hb;
             } else {

@@ -322,7 +322,9 @@ def as_nhwc(t: torch.Tensor, cpad: int = 4) -> torch.Tensor:
     buf = torch.empty((b, h, w, cp), device=t.device, dtype=torch.float32)
     full = buf.permute(0, 3, 1, 2)
     copy4d(t, full, cp)
-    return full if cp == c else full[:, :c]
+    out = full if cp == c else full[:, :c]
+    out._fusg_zero_pad = True              # (this very object: its padding channels were zero-filled just now)
+    return out
 
 
 def to_nchw(t: torch.Tensor) -> torch.Tensor:

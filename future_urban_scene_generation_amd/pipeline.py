@@ -1037,8 +1037,12 @@ def synth_clip(vehicles: int, frames: int, res: int, device, seed: int = 0) -> D
             "vu_y": synth_inputs("vunet", vehicles * frames, res, seed + 1)["y_tilde"].view(vehicles, frames, 3, res, res).to(device)}
 
 
-def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Synthetic, device-resident inputs of the shapes/ranges the reference feeds."""
+def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int = 0, nhwc: bool = False) -> Dict[str, torch.Tensor]:
+    """Synthetic, device-resident inputs of the shapes/ranges the reference feeds.
+    nhwc=True (CUDA devices): the tensors are handed over in the layout the frame driver's glue kernels write and the
+    stems read in place - NHWC-physical, channel pitch padded with zeros to the stem's K-channels (4 / 24 / 8 / 4; logical
+    shape and values unchanged) - so a pass starts without the four NCHW -> NHWC conversion launches a caller with
+    standard-contiguous tensors pays (`ops.as_nhwc` at every network's entry)."""
     from .synth import synth_inputs
     b = {"hg_x": synth_inputs("hg", batch, res, seed)["x"], "icn_x": synth_inputs("icn", batch, res, seed)["x"]}
     v = synth_inputs("vunet", batch, res, seed)
@@ -1046,7 +1050,14 @@ def synth_batch(batch: int, res: int, device, inpaint: bool = False, seed: int =
     if inpaint:
         e = synth_inputs("edge", batch, res, seed)
         b.update(ec_img=e["img"], ec_gray=e["gray"], ec_edge=e["edge"], ec_mask=e["mask"])
-    return {k: t.to(device) for k, t in b.items()}
+    out = {k: t.to(device) for k, t in b.items()}
+    if nhwc and torch.device(device).type == "cuda":
+        from . import ops
+        pitch = {"hg_x": 4, "icn_x": 24, "vu_x": 8, "vu_y": 4}
+        with torch.cuda.device(device):
+            for k, cp in pitch.items():
+                out[k] = ops.as_nhwc(out[k].contiguous(), cpad=cp)
+    return out
 
 
 def synth_frame(vehicles: int, frame_hw=(720, 1280), device="cuda", seed: int = 0, inpaint: bool = False) -> Dict:
