@@ -182,14 +182,64 @@ class Vunet_fix_res(FusedNet):
         return P
 
     # ------------------------------------------------------------------ fused building blocks
-    def _residual(self, name: str, x, skip=None):
-        return ops.conv(self._plans[name + ".layers.2"], x, skip, pre_op=L.PRE_ELU, res0=x)
+    def _residual(self, name: str, x, skip=None, out=None):
+        return ops.conv(self._plans[name + ".layers.2"], x, skip, pre_op=L.PRE_ELU, res0=x, out=out)
 
-    def _nin(self, name: str, x, x1=None):
-        return ops.conv(self._plans[name + ".layers.1"], x, x1, pre_op=L.PRE_ELU)
+    def _nin(self, name: str, x, x1=None, out=None):
+        return ops.conv(self._plans[name + ".layers.1"], x, x1, pre_op=L.PRE_ELU, out=out)
 
     def _upsample(self, name: str, x):
         return ops.conv(self._plans[name + ".depth4x"], x, store=L.STORE_D2S)
+
+    # ---- "fusion by cache blocking" of the high-resolution 32-channel blocks (round 4 experiment, FUSG_VU_SUBBATCH=n) ----
+    # The verdict's fused Residual -> Residual block would keep the intermediates of the 256 x 256 / 128 x 128 levels out of
+    # HBM.  The same traffic saving without a new kernel: run those levels depth-first over sub-batches of n images, so that
+    # every intermediate (67 MB per tensor at n = 8, 32 channels, 256 x 256) is consumed out of the 256 MiB Infinity Cache
+    # right after it was written, and the sub-batch temporaries are the same allocator blocks every time.  Same launches on
+    # slices: the results are bit-identical.  Measured: profiles/r04_ab_experiments.txt.
+    @staticmethod
+    def _subbatch(b: int) -> int:
+        import os
+        n = int(os.environ.get("FUSG_VU_SUBBATCH", "0"))
+        return n if 0 < n < b else 0
+
+    def _shape_encoder_top(self, x, n):
+        """forward_dec_up's first two levels (InitBlock at full resolution, DownBlock 1_a at half) over sub-batches of n."""
+        b, _, h, w = x.shape
+        dev = x.device
+        sb, sc = ops.nhwc_empty(b, 32, h, w, dev), ops.nhwc_empty(b, 32, h, w, dev)
+        ab, ac = ops.nhwc_empty(b, 32, h // 2, w // 2, dev), ops.nhwc_empty(b, 32, h // 2, w // 2, dev)
+        a1 = ops.nhwc_empty(b, 32, h // 2, w // 2, dev)
+        for lo in range(0, b, n):
+            hi = min(b, lo + n)
+            t = self._nin("shape_encoder_1.nin", x[lo:hi])
+            s0 = self._residual("shape_encoder_1.residual_0", t)
+            s1 = self._residual("shape_encoder_1.residual_1", s0)
+            self._nin("shape_skip_1_b", s0, out=sb[lo:hi])
+            self._nin("shape_skip_1_c", s1, out=sc[lo:hi])
+            d = ops.conv(self._plans["shape_encoder_1_a.down.down"], s1)
+            a0 = self._residual("shape_encoder_1_a.residual_0", d)
+            self._residual("shape_encoder_1_a.residual_1", a0, out=a1[lo:hi])
+            self._nin("shape_skip_1_a_b", a0, out=ab[lo:hi])
+            self._nin("shape_skip_1_a_c", a1[lo:hi], out=ac[lo:hi])
+        return a1, [sb, sc, ab, ac]
+
+    def _shape_decoder_tail(self, x, skips, n):
+        """forward_dec_down's last two blocks (UpBlock 5_a at half resolution, EndBlock at full) over sub-batches of n;
+        `skips` = [skip_a, skip_b] of 5_a, then of the EndBlock (full-batch tensors)."""
+        b, _, h, w = x.shape
+        head = self._plans["shape_decoder_6.conv"]
+        out = torch.empty((b, 3, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+        for lo in range(0, b, n):
+            hi = min(b, lo + n)
+            r = self._residual("shape_decoder_5_a.residual_0", x[lo:hi], skips[0][lo:hi])
+            r = self._residual("shape_decoder_5_a.residual_1", r, skips[1][lo:hi])
+            u = self._upsample("shape_decoder_5_a.up", r)
+            e = self._residual("shape_decoder_6.residual_0", u, skips[2][lo:hi])
+            e = self._residual("shape_decoder_6.residual_1", e, skips[3][lo:hi])
+            o = ops.conv_rowsplit(head, e, nchw_out=True) if head.rowsplit is not None else ops.conv(head, e, nchw_out=True)
+            ops.copy4d(o, out[lo:hi], 0)                      # (3 channels: a 6 MB copy per sub-batch)
+        return out
 
     def set_vehicle_seeds(self, seeds=None):
         """Optional, beyond the reference: give every sample of the next passes its own noise stream
@@ -343,11 +393,15 @@ class Vunet_fix_res(FusedNet):
         self._ensure(x)
         x = ops.as_nhwc(x)
         skips: List[torch.Tensor] = []
-        x, sl = self._init_block("shape_encoder_1", x)
-        skips += [self._nin("shape_skip_1_b", sl[-2]), self._nin("shape_skip_1_c", sl[-1])]
-        if self.vunet_256:
-            x, sl = self._down_block("shape_encoder_1_a", x)
-            skips += [self._nin("shape_skip_1_a_b", sl[-2]), self._nin("shape_skip_1_a_c", sl[-1])]
+        nsub = self._subbatch(x.shape[0]) if self.vunet_256 else 0
+        if nsub:
+            x, skips = self._shape_encoder_top(x, nsub)
+        else:
+            x, sl = self._init_block("shape_encoder_1", x)
+            skips += [self._nin("shape_skip_1_b", sl[-2]), self._nin("shape_skip_1_c", sl[-1])]
+            if self.vunet_256:
+                x, sl = self._down_block("shape_encoder_1_a", x)
+                skips += [self._nin("shape_skip_1_a_b", sl[-2]), self._nin("shape_skip_1_a_c", sl[-1])]
         for i in range(2, 7):
             x, sl = self._down_block(f"shape_encoder_{i}", x)
             skips += [self._nin(f"shape_skip_{i}_b", sl[-2]), self._nin(f"shape_skip_{i}_c", sl[-1])]
@@ -390,12 +444,17 @@ class Vunet_fix_res(FusedNet):
             x = self._nin(f"shape_decoder_{blk}_n", x, z_k)
             x = self._residual(f"shape_decoder_{blk}_o", x, skip_b)
             x = self._upsample(f"shape_decoder_{blk}_p", x)
+        nsub = self._subbatch(x0.shape[0]) if self.vunet_256 else 0
         names = ["shape_decoder_3", "shape_decoder_4", "shape_decoder_5"] + \
-                (["shape_decoder_5_a"] if self.vunet_256 else [])
+                (["shape_decoder_5_a"] if (self.vunet_256 and not nsub) else [])
         for n in names:
             skip_a = ops.as_nhwc(skips.pop())
             skip_b = ops.as_nhwc(skips.pop())
             x = self._up_block(n, x, skip_a, skip_b)
+        if nsub:
+            tail = [ops.as_nhwc(skips.pop()) for _ in range(4)]
+            assert not skips
+            return self._shape_decoder_tail(x, tail, nsub), mu, z
         skip_a = ops.as_nhwc(skips.pop())
         skip_b = ops.as_nhwc(skips.pop())
         x = self._residual("shape_decoder_6.residual_0", x, skip_a)
