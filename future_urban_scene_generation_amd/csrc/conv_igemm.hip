@@ -145,14 +145,14 @@ const float* zero_line() {
 
 // Does this launch take the small-spatial kernel (conv_kernel_small.h), and with which K ranges?  Shared by the planner
 // (workspace size) and the launcher.
-struct SmallCfg { int nimg, rpi, rpi_shift, RIN, WIN, NPIX, nchw, ksplit, nch32, ntaps; };
+struct SmallCfg { int nimg, rpi, rpi_shift, tpi, wide, RIN, WIN, NPIX, nchw, ksplit, nch32, ntaps; long mt; };
 static bool small_cfg(const fusg_conv_desc* d, int precision, SmallCfg* out) {
     // (FUSG_NO_SMALL is read per call: tests and the A/B tools flip it at run time)
     if (getenv("FUSG_NO_SMALL") != nullptr || env_switches().no_halo) return false;
     const int nphase = d->nphase > 0 ? d->nphase : 1;
     if (precision != FUSG_PREC_F16X3 || nphase != 1 || d->kh < 1 || d->kw < 1 || d->kh > 3 || d->kw > 3 || d->dil != 1 ||
-        d->pad_mode != FUSG_PAD_ZERO || d->upsample != 0 || (d->stride != 1 && d->stride != 2) || d->tile_list || d->stats_out ||
-        (d->q_oy | d->q_ox) != 0 || !d->wfrag || (((uintptr_t)d->wfrag) & 15) != 0 || (d->wfrag_order != 0 && d->wfrag_order != 1))
+        (d->pad_mode != FUSG_PAD_ZERO && d->pad_mode != FUSG_PAD_REPLICATE) || d->upsample != 0 || (d->stride != 1 && d->stride != 2) ||
+        d->tile_list || d->stats_out || !d->wfrag || (((uintptr_t)d->wfrag) & 15) != 0 || (d->wfrag_order != 0 && d->wfrag_order != 1))
         return false;
     const int ntaps = d->kh * d->kw;
     if (d->c0k <= 0 || d->c0k % 32 || d->k_pad % ntaps) return false;
@@ -160,26 +160,43 @@ static bool small_cfg(const fusg_conv_desc* d, int precision, SmallCfg* out) {
     if (c1k < 0 || c1k % 32 || (c1k > 0 && !d->src1.data)) return false;
     if (d->wfrag_order == 1 && !(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1)) return false;
     const int Ho = d->qh, Wo = d->qw, hw = Ho * Wo;
-    if (hw > env_switches().small_maxhw) return false;
+    // a WINDOW of a larger output (the ring launches of the ICN's up-convolutions: one edge row / column / corner) can use no
+    // other fast kernel, whatever its size; whole images only up to small_maxhw pixels (beyond, the halo kernel is faster)
+    const long full_h = (d->src0.h + 2L * d->pad_h - d->kh) / d->stride + 1, full_w = (d->src0.w + 2L * d->pad_w - d->kw) / d->stride + 1;
+    const bool part = (d->q_oy | d->q_ox) != 0 || Ho != full_h || Wo != full_w;
+    const bool window = part && d->pad_mode == FUSG_PAD_REPLICATE;     // (zero padding: whole images only - q_size launches keep their kernels)
+    if (part && !window) return false;
+    if (!window && hw > env_switches().small_maxhw) return false;
     SmallCfg c;
-    if (hw >= SMALL_ROWS) {
-        if (hw % SMALL_ROWS || SMALL_ROWS % Wo) return false;
-        c.nimg = 1; c.rpi = SMALL_ROWS;
-        c.RIN = (SMALL_ROWS / Wo - 1) * d->stride + d->kh;
-    } else {
-        if (SMALL_ROWS % hw) return false;
+    c.tpi = 1; c.wide = 0; c.rpi = SMALL_ROWS; c.rpi_shift = 5;
+    const long B = d->src0.n;
+    if (hw < SMALL_ROWS && SMALL_ROWS % hw == 0 && !window) {          // several whole images per workgroup
         c.nimg = SMALL_ROWS / hw; c.rpi = hw;
+        c.rpi_shift = 0;
+        while ((1 << c.rpi_shift) < c.rpi) ++c.rpi_shift;
         c.RIN = (Ho - 1) * d->stride + d->kh;
+        c.WIN = (Wo - 1) * d->stride + d->kw;
+        c.mt = (B + c.nimg - 1) / c.nimg;
+    } else {                                                            // runs of 32 pixels of one image (the last run of an image may be short)
+        c.nimg = 1;
+        c.tpi = (hw + SMALL_ROWS - 1) / SMALL_ROWS;
+        if (Wo >= SMALL_ROWS) {
+            if (!(Ho == 1 || Wo % SMALL_ROWS == 0)) return false;       // a run must stay inside one output row
+            c.wide = 1;
+            c.RIN = d->kh;
+            c.WIN = (SMALL_ROWS - 1) * d->stride + d->kw;
+        } else {
+            if (SMALL_ROWS % Wo) return false;
+            c.RIN = (SMALL_ROWS / Wo - 1) * d->stride + d->kh;
+            c.WIN = (Wo - 1) * d->stride + d->kw;
+        }
+        c.mt = B * c.tpi;
     }
-    c.rpi_shift = 0;
-    while ((1 << c.rpi_shift) < c.rpi) ++c.rpi_shift;
-    if ((1 << c.rpi_shift) != c.rpi) return false;
-    c.WIN = (Wo - 1) * d->stride + d->kw;
     c.NPIX = c.nimg * c.RIN * c.WIN;
     if (c.NPIX > SMALL_MAXPIX) return false;
     c.nch32 = ctot / 32; c.ntaps = ntaps;
-    // chunks per K range: the staged image must fit (<= 96 KiB) and a wave should not need more than two rounds of weights
-    int nchw = (96 * 1024) / (c.NPIX * 128);
+    // chunks per K range: the staged image must fit (<= 112 KiB) and a wave should not need more than two rounds of weights
+    int nchw = (112 * 1024) / (c.NPIX * 128);
     const int by_rounds = (2 * 4 * SMALL_NS) / ntaps;
     if (by_rounds < nchw) nchw = by_rounds;
     if (nchw < 1) return false;
@@ -436,14 +453,15 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             } else {
                 for (int tp = 0; tp < sc.ntaps; ++tp) h.tapslab |= (unsigned long long)tp << (4 * tp);
             }
-            h.nchw = sc.nchw; h.nimg = sc.nimg; h.rpi = sc.rpi; h.rpi_shift = sc.rpi_shift;
+            h.nchw = sc.nchw; h.nimg = sc.nimg; h.rpi = sc.rpi; h.rpi_shift = sc.rpi_shift; h.tpi = sc.tpi; h.wide = sc.wide;
+            h.pad_mode = d->pad_mode;
             h.RIN = sc.RIN; h.WIN = sc.WIN; h.NPIX = sc.NPIX;
             auto magic = [](int dv) -> unsigned { return dv < 2 ? 0u : (unsigned)(((1UL << 32) + (unsigned long)dv - 1) / (unsigned long)dv); };
             h.m_wo = magic(d->qw); h.m_hw = magic(d->qh * d->qw); h.m_win = magic(sc.WIN); h.m_rw = magic(sc.RIN * sc.WIN);
-            h.m_npix = magic(sc.NPIX); h.m_taps = magic(sc.ntaps); h.m_ihw = magic((int)(x0.h * x0.w));
+            h.m_npix = magic(sc.NPIX); h.m_taps = magic(sc.ntaps); h.m_ihw = magic((int)(x0.h * x0.w)); h.m_tpi = magic(sc.tpi);
             // (the reciprocals are exact while dividend * divisor < 2^32: the largest dividend is a source pixel index)
             if ((long)x0.n * x0.h * x0.w * (x0.h * x0.w) < (1L << 32) && Ml * (long)(d->qh * d->qw) < (1L << 32)) {
-                h.c.MT = (int)((Ml + SMALL_ROWS - 1) / SMALL_ROWS); h.c.NT = d->cout_pad / 32;
+                h.c.MT = (int)sc.mt; h.c.NT = d->cout_pad / 32;
                 h.c.ksplit = sc.ksplit;
                 dim3 sgrid(h.c.MT * h.c.NT, 1, sc.ksplit);
                 e = launch_small(h, sgrid, s, pk);

@@ -43,11 +43,14 @@ struct SmallK {
     const _Float16* wfrag;      // [slab][chunk][cout_pad/32][16-column half][hi|lo][64 lanes][8] halves
     int nt32;
     int nchw;                   // chunks per K range (gridDim.z ranges)
-    int nimg;                   // images a workgroup's 32 rows span (1: rows of one image)
-    int rpi;                    // output rows (pixels) per image taken by one workgroup = 32 / nimg
+    int nimg;                   // images a workgroup's 32 rows span (1: a run of pixels of ONE image)
+    int rpi;                    // nimg > 1: output pixels per image (= Ho * Wo, a power of two)
+    int tpi;                    // nimg == 1: 32-row tiles per image = ceil(Ho * Wo / 32) (the last one may be ragged)
+    int wide;                   // nimg == 1: 1 = a tile is a 32-pixel segment of one output row (Wo >= 32), 0 = 32 / Wo whole rows
+    int pad_mode;               // FUSG_PAD_ZERO or FUSG_PAD_REPLICATE (clamped coordinates: the ring windows of the ICN's up-convolutions)
     int RIN, WIN, NPIX;         // staged region per image (rows, columns), pixels in all = nimg * RIN * WIN
     int rpi_shift;              // log2(rpi)
-    unsigned m_wo, m_hw, m_win, m_rw, m_npix, m_taps, m_ihw;   // reciprocals (sdiv) of Wo, Ho*Wo, WIN, RIN*WIN, NPIX, ntaps, H*W
+    unsigned m_wo, m_hw, m_win, m_rw, m_npix, m_taps, m_ihw, m_tpi;   // reciprocals (sdiv) of Wo, Ho*Wo, WIN, RIN*WIN, NPIX, ntaps, H*W, tpi
     int part_off;               // byte offset of the partial tiles in dynamic LDS
 };
 
@@ -62,8 +65,18 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     const int tile = blockIdx.x;
     const int mt = tile / p.NT, nt = tile - mt * p.NT;
     const int ks = blockIdx.z;
-    const int m0 = mt * SMALL_ROWS;
     const int hw = p.Ho * p.Wo;
+    // the workgroup's 32 rows: nimg == 1: pixels p0 .. p0 + 31 of image b0's (window of the) output, row-major - a segment of
+    // one row (wide) or 32 / Wo whole rows; nimg > 1: the whole outputs of images b0 .. b0 + nimg - 1
+    int b0, p0 = 0, oy_t = 0, ox_t = 0;
+    if (sk.nimg == 1) {
+        b0 = sdiv(mt, sk.m_tpi);
+        p0 = (mt - b0 * sk.tpi) * SMALL_ROWS;
+        oy_t = sdiv(p0, sk.m_wo);
+        ox_t = sk.wide ? p0 - oy_t * p.Wo : 0;
+    } else {
+        b0 = mt * sk.nimg;
+    }
     const int cg0 = ks * sk.nchw;
     const int nmine = min(sk.nch32 - cg0, sk.nchw);            // >= 1 (host: every range is non-empty)
     const int nsteps = nmine * sk.ntaps;
@@ -105,11 +118,11 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     if (t < NPIX) {
         const int j = sdiv(t, sk.m_rw), q = t - j * (sk.RIN * sk.WIN);
         const int ry = sdiv(q, sk.m_win), rx = q - ry * sk.WIN;
-        int b, oy0;
-        if (sk.nimg == 1) { b = sdiv(m0, sk.m_hw); oy0 = sdiv(m0 - b * hw, sk.m_wo); }
-        else { b = sdiv(m0, sk.m_hw) + j; oy0 = 0; }
-        const int iy = oy0 * sk.stride - sk.pad_h + ry, ix = rx - sk.pad_w;
-        const bool ok = b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int b = b0 + j;
+        int iy = (oy_t + p.qy0) * sk.stride - sk.pad_h + ry, ix = (ox_t + p.qx0) * sk.stride - sk.pad_w + rx;
+        bool ok = b < p.B;
+        if (sk.pad_mode == FUSG_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
+        else ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         pixsrc[t] = ok ? (b * p.H + iy) * p.W + ix : -1;
     }
     __syncthreads();
@@ -171,8 +184,9 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     for (int f = 0; f < 2; ++f) {
         const int r = f * 16 + (lane & 15);
         int j = 0, rem = r;
-        if (sk.nimg > 1) { j = r >> sk.rpi_shift; rem = r - (j << sk.rpi_shift); }
-        const int oyl = sdiv(rem, sk.m_wo), ox = rem - oyl * p.Wo;
+        if (sk.nimg > 1) { j = min(r >> sk.rpi_shift, sk.nimg - 1); rem = r & (sk.rpi - 1); }      // (rows past the last image: masked below)
+        int oyl = 0, ox = rem;
+        if (!(sk.nimg == 1 && sk.wide)) { oyl = sdiv(rem, sk.m_wo); ox = rem - oyl * p.Wo; }
         abase[f] = (j * sk.RIN + oyl * sk.stride) * sk.WIN + ox * sk.stride;
     }
     __syncthreads();                                             // the staged image is complete (and pixsrc is dead)
@@ -186,8 +200,11 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
     // ---- the epilogue's operands (bias, weight scale, residuals of this thread's (row, 4 columns)) are fetched NOW, so that
     // their round trip overlaps the contraction instead of following it
     const int row = t >> 3, c4 = t & 7;
-    const int m = m0 + row, n = nt * 32 + c4 * 4;
-    const bool live = m < p.M && n < p.Cout && p.ksplit <= 1;
+    const int n = nt * 32 + c4 * 4;
+    int m;                                                       // this thread's output row in the launch's M = B * Ho * Wo, or -1
+    if (sk.nimg == 1) m = p0 + row < hw ? b0 * hw + p0 + row : -1;
+    else { const int j = row >> sk.rpi_shift; m = (j < sk.nimg && b0 + j < p.B) ? (b0 + j) * hw + (row & (sk.rpi - 1)) : -1; }
+    const bool live = m >= 0 && n < p.Cout && p.ksplit <= 1;
     PixOff po, co;
     po.d = po.r0 = po.r1 = 0;
     co.d = co.r0 = co.r1 = 0;
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
             for (int r = 0; r < 4; ++r)
                 part[(wave * 32 + f * 16 + (lane >> 4) * 4 + r) * 32 + ct * 16 + (lane & 15)] = acc[f][ct][r];
     __syncthreads();
-    if (m >= p.M) return;
+    if (m < 0) return;
     f32x4 s = *(const f32x4*)(part + row * 32 + c4 * 4);
 #pragma unroll
     for (int w = 1; w < 4; ++w) s += *(const f32x4*)(part + (w * 32 + row) * 32 + c4 * 4);

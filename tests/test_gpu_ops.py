@@ -968,3 +968,27 @@ def test_f32_halo_kernel(B, c0, c1, cout, k, stride, pad, dil, pm, H, W, pre, pr
     assert e_new <= max(2 * e_old, 5e-7), (e_new, e_old)
     _close(got, old.cpu(), rtol=1e-5, atol=2e-6 * scale)
     assert torch.equal(got, ops.conv(plan, a0, a1, **kw))          # deterministic
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 256, 128, 16, 32), (3, 128, 64, 32, 32), (1, 64, 32, 8, 16)])
+def test_conv_up2_ring_on_the_small_image_kernel(B, cin, cout, H, W, precision):
+    """ICN decoder, Upsample(2) -> reflect 5x5: the outermost ring of the output as twelve 3x3 launches with border-regrouped
+    weights (pack.pack_conv_up2_ring, 9 MACs per output instead of 25) - windows of one edge row / column / corner, replicate
+    padding - which the small-image kernel takes as runs of 32 pixels of a window (round 4).  Equals torch, and (f16x3) the last
+    ring launch really ran on that kernel."""
+    x = _rand(B, cin, H, W, seed=1)
+    w = _rand(cout, cin, 5, 5, seed=2, scale=1.0 / (cin * 25) ** 0.5)
+    b = _rand(cout, seed=3)
+    sc, sh = torch.rand(B, cin, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(B, cin, seed=5) * 0.2
+    exact = pack.pack_conv(w, b, pad=2, pad_mode=1, upsample=1)
+    ring = {k: v.to(dev()) for k, v in pack.pack_conv_up2_ring(w, b).items()}
+    xin = torch.relu(x * sc[:, :, None, None] + sh[:, :, None, None])
+    ref = F.conv2d(F.pad(F.interpolate(xin, scale_factor=2, mode="nearest"), (2,) * 4, mode="reflect"), w, b)
+    pre = (sc.to(dev()).contiguous(), sh.to(dev()).contiguous())
+    xd = _nhwc(x)
+    got = ops.conv_up2(exact, pack.pack_conv_up2_d2s(w, b), xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin, ring=ring)
+    if precision == "f16x3":
+        assert ops.last_conv_kernel() == 8, ops.last_conv_kernel()
+    _close(got, ref)
+    want = ops.conv_up2(exact, pack.pack_conv_up2_d2s(w, b), xd, pre_op=L.PRE_AFFINE_RELU, pre=pre, pre_bstride=cin)   # 25-tap windows
+    _close(got, want.cpu(), rtol=1e-4, atol=1e-4)
