@@ -54,7 +54,7 @@ class BneckDesc(C.Structure):           # fusg_bneck_desc
                 ("w1frag", C.c_void_p), ("bias1", C.c_void_p), ("wscale1", C.c_void_p),
                 ("w2frag", C.c_void_p), ("bias2", C.c_void_p), ("wscale2", C.c_void_p),
                 ("w3frag", C.c_void_p), ("bias3", C.c_void_p), ("wscale3", C.c_void_p),
-                ("status", C.c_void_p), ("planes", C.c_int32), ("_pad", C.c_int32)]
+                ("status", C.c_void_p), ("planes", C.c_int32), ("exact_f32", C.c_int32)]
 
 
 class PackSpec(C.Structure):            # fusg_pack_spec

@@ -342,6 +342,249 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     }
 }
 
+
+// ---- the same block in EXACT fp32 (fusg_bneck_desc.exact_f32 = 1; round 4): v_mfma_f32_16x16x4_f32, weights as the A
+// operand (lane (n = l & 15, g = l >> 4) feeds w[n][16 h + 4 g + e] to instruction (h, e) of a 32-channel chunk: the fp32
+// fragment copy of pack.frag_f32, two 16-byte loads per 16-channel tile and chunk), pixels as B (the lane's pixel, channels
+// 16 h + 4 g + e: two 16-byte LDS reads per fragment and chunk).  The LDS images hold fp32 - 128 bytes per pixel and chunk,
+// the bytes of the (hi, lo) pair - unswizzled: the matrix pipe is 16x slower per FLOP than in fp16 and LDS is idle.
+// Same structure, phases, barriers and register tiling as hg_bneck_h3; no weight scales, no range status.
+template <int CT> struct WFragF { f32x4 f[CT][2]; };    // [16-channel tile][h]
+
+template <int P>
+__global__ __launch_bounds__(256, 2) void hg_bneck_f32(const BneckK k) {
+    constexpr int NCH = P / 32;
+    constexpr int CT1 = P / 64, CT3 = P / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* S = smem_f;                                   // conv1's operand, one 32-channel chunk: [112][32]
+    float* T = S + BN_SROWS * 32;                       // conv1's output on the halo: [NCH][100][32]
+    float* U = T;                                        // conv2's output on the patch: [NCH][64][32] (overlays T)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lp = lane & 15, lg = lane >> 4;
+    int tile;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, j = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tpi = k.tiles_x * k.tiles_y;
+    const int b = tile / tpi, t2 = tile - b * tpi;
+    const int ty = t2 / k.tiles_x, tx = t2 - ty * k.tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 8;
+    const float* w1 = (const float*)k.w1; const float* w2 = (const float*)k.w2; const float* w3 = (const float*)k.w3;
+
+    // ------------------------------------------------------------------ conv1 on the halo
+    const int kc = t & 7;
+    const float* xp[4];
+    int soff[4];
+    unsigned sval = 0, sexist = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int item = t + 256 * j, pix = item >> 3;
+        xp[j] = k.zeros;
+        soff[j] = 0;
+        if (item < BN_SROWS * 8) {
+            sexist |= 1u << j;
+            soff[j] = pix * 32 + kc * 4;
+            if (pix < BN_HP) {
+                const int hy = pix / 10, hx = pix - hy * 10;
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                if ((unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W) {
+                    sval |= 1u << j;
+                    xp[j] = k.x + (long)b * k.xsn + (long)iy * k.xsh + (long)ix * k.xsw + kc * 4;
+                }
+            }
+        }
+    }
+    f32x4 hreg[4], sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int c) {
+        sc = *(const f32x4*)(k.pre_scale + c * 32 + kc * 4);
+        sh = *(const f32x4*)(k.pre_shift + c * 32 + kc * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hreg[j] = *(const f32x4*)(((sval >> j) & 1u) ? xp[j] + c * 32 : k.zeros);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = hreg[j];
+            const bool ok = (sval >> j) & 1u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float y = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f); v[c] = ok ? y : 0.f; }   // bn1 + ReLU
+            if ((sexist >> j) & 1u) *(f32x4*)(S + soff[j]) = v;
+        }
+    };
+    // fp32 fragments of 16-channel tiles gct0 .. of slab `slab`: [slab][nt32][16-channel half][h][64 lanes][4 floats]
+    auto load_w = [&](auto& F, const float* w, int slab, int nt32, int gct0) {
+        constexpr int CT = sizeof(F.f) / sizeof(F.f[0]);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int gct = gct0 + j;
+            const float* p = w + ((long)((slab * nt32 + (gct >> 1)) * 2 + (gct & 1)) * 2) * 256 + lane * 4;
+            F.f[j][0] = *(const f32x4*)(p);
+            F.f[j][1] = *(const f32x4*)(p + 256);
+        }
+    };
+    // one (row group of 16 pixels) x (CT tiles) x (32-channel chunk) contraction: xa / xb = the pixel's channels 4 g .. and 16 + 4 g ..
+    auto mac = [&](auto& acc_row, const auto& F, const f32x4 xa, const f32x4 xb) __attribute__((always_inline)) {
+        constexpr int CT = sizeof(F.f) / sizeof(F.f[0]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc_row[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j][h][e], h ? xb[e] : xa[e], acc_row[j], 0, 0, 0);
+    };
+
+    f32x4 acc1[7][CT1];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sfrag = lp * 32 + lg * 4;                          // + rg * 512: this lane's first fragment half in S / U
+    auto compute1 = [&](const WFragF<CT1>& F) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const f32x4 xa = *(const f32x4*)(S + i * 512 + sfrag), xb = *(const f32x4*)(S + i * 512 + sfrag + 16);
+            mac(acc1[i], F, xa, xb);
+        }
+    };
+
+    const int nch1 = k.Cin >> 5;
+    WFragF<CT1> wA, wB;
+    issue(0);
+    load_w(wA, w1, 0, NCH, wave * CT1);
+    for (int c = 0; c < nch1; c += 2) {
+        commit();
+        __syncthreads();
+        if (c + 1 < nch1) { issue(c + 1); load_w(wB, w1, c + 1, NCH, wave * CT1); }
+        compute1(wA);
+        __syncthreads();
+        if (c + 1 >= nch1) break;
+        commit();
+        __syncthreads();
+        if (c + 2 < nch1) { issue(c + 2); load_w(wA, w1, c + 2, NCH, wave * CT1); }
+        compute1(wB);
+        __syncthreads();
+    }
+
+    WFragF<CT1> w0, w1f, w2f;
+    load_w(w0, w2, 0, NCH, wave * CT1);
+    load_w(w1f, w2, NCH, NCH, wave * CT1);
+    {   // conv1's result (+ bias, ReLU; zero outside the image = conv2's padding) -> T
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) {
+            const int gct = wave * CT1 + j;
+            const int n0 = gct * 16 + lg * 4;
+            const f32x4 bias = *(const f32x4*)(k.b1 + n0);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int pix = i * 16 + lp;
+                const int hy = pix / 10, hx = pix - hy * 10;
+                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                const bool ok = pix < BN_HP && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float y = fmaxf(acc1[i][j][r] + bias[r], 0.f); v[r] = ok ? y : 0.f; }
+                if (pix < BN_HP) *(f32x4*)(T + ((gct >> 1) * BN_HP + pix) * 32 + (gct & 1) * 16 + lg * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ conv2: 3x3 over T
+    f32x4 acc2[4][CT1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int prow = lp >> 3, pcol = lp & 7;
+    const int tfrag = (prow * 10 + pcol) * 32 + lg * 4;          // + rg * 640
+    auto compute2 = [&](const WFragF<CT1>& F, int c, int tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int o = c * (BN_HP * 32) + tfrag + (ky * 10 + kx) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 xa = *(const f32x4*)(T + o + i * 640), xb = *(const f32x4*)(T + o + i * 640 + 16);
+            mac(acc2[i], F, xa, xb);
+        }
+    };
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap += 3) {
+            const int s2 = c * 9 + tap + 2;
+            auto slab_of = [](int s) { const int cc = s / 9; return (s - cc * 9) * NCH + cc; };
+            load_w(w2f, w2, slab_of(s2), NCH, wave * CT1);
+            compute2(w0, c, tap);
+            if (s2 + 1 < NCH * 9) load_w(w0, w2, slab_of(s2 + 1), NCH, wave * CT1);
+            compute2(w1f, c, tap + 1);
+            if (s2 + 2 < NCH * 9) load_w(w1f, w2, slab_of(s2 + 2), NCH, wave * CT1);
+            compute2(w2f, c, tap + 2);
+        }
+    }
+    __syncthreads();                                            // T is dead: U may overwrite it
+
+    WFragF<CT3> v0, v1;
+    load_w(v0, w3, 0, 2 * NCH, wave * CT3);
+    {
+#pragma unroll
+        for (int j = 0; j < CT1; ++j) {
+            const int gct = wave * CT1 + j;
+            const int n0 = gct * 16 + lg * 4;
+            const f32x4 bias = *(const f32x4*)(k.b2 + n0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[i][j][r] + bias[r], 0.f);
+                // pixel i * 16 + lp of the patch in U's order = fragment order of conv2's row groups (2 rows x 8 columns)
+                *(f32x4*)(U + ((gct >> 1) * 64 + i * 16 + lp) * 32 + (gct & 1) * 16 + lg * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ conv3: 1x1 P -> 2 P
+    f32x4 acc3[4][CT3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < CT3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute3 = [&](const WFragF<CT3>& F, int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 xa = *(const f32x4*)(U + c * 2048 + i * 512 + sfrag), xb = *(const f32x4*)(U + c * 2048 + i * 512 + sfrag + 16);
+            mac(acc3[i], F, xa, xb);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; c += 2) {
+        load_w(v1, w3, c + 1, 2 * NCH, wave * CT3);
+        compute3(v0, c);
+        if (c + 2 < NCH) load_w(v0, w3, c + 2, 2 * NCH, wave * CT3);
+        compute3(v1, c + 1);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = oy0 + 2 * i + prow, ox = ox0 + pcol;
+        if (oy >= k.H || ox >= k.W) continue;
+        const float* rp = k.res + (long)b * k.rsn + (long)oy * k.rsh + (long)ox * k.rsw;
+        float* dp = k.dst + (long)b * k.dsn + (long)oy * k.dsh + (long)ox * k.dsw;
+#pragma unroll
+        for (int j = 0; j < CT3; ++j) {
+            const int n0 = (wave * CT3 + j) * 16 + lg * 4;
+            const f32x4 bias = *(const f32x4*)(k.b3 + n0);
+            const f32x4 r = *(const f32x4*)(rp + n0);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc3[i][j][e] + bias[e]) + r[e];
+            *(f32x4*)(dp + n0) = v;
+        }
+    }
+}
+
 }  // namespace fusg
 
 using namespace fusg;
@@ -356,10 +599,15 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     FUSG_CHECK(is_nhwc(d->res) && is_nhwc(d->dst) && same_nhw(x, d->res) && same_nhw(x, d->dst) && d->res.c == 2 * P &&
                d->dst.c == 2 * P, "hg_bottleneck: res / dst must be NHWC-physical f32 [n, 2 * planes, h, w] like x");
     FUSG_CHECK(x.data != d->dst.data && d->res.data != d->dst.data, "hg_bottleneck: dst must not alias x or res (neighbouring patches read x's halo)");
-    const void* ptrs[] = {d->pre_scale, d->pre_shift, d->w1frag, d->bias1, d->wscale1, d->w2frag, d->bias2, d->wscale2,
-                          d->w3frag, d->bias3, d->wscale3};
+    const bool f32 = d->exact_f32 == 1;
+    FUSG_CHECK(d->exact_f32 == 0 || d->exact_f32 == 1, "hg_bottleneck: exact_f32 %d", d->exact_f32);
+    const void* ptrs[] = {d->pre_scale, d->pre_shift, d->w1frag, d->bias1, d->w2frag, d->bias2, d->w3frag, d->bias3};
     for (const void* p : ptrs) FUSG_CHECK(p && (((uintptr_t)p) & 15) == 0, "hg_bottleneck: a parameter array is missing or not 16-byte aligned");
-    FUSG_CHECK(d->status != nullptr, "hg_bottleneck: status word missing");
+    if (!f32) {
+        const void* sp[] = {d->wscale1, d->wscale2, d->wscale3};
+        for (const void* p : sp) FUSG_CHECK(p && (((uintptr_t)p) & 15) == 0, "hg_bottleneck: a weight-scale array is missing or not 16-byte aligned");
+        FUSG_CHECK(d->status != nullptr, "hg_bottleneck: status word missing");
+    }
     FUSG_CHECK(x.n * x.h * x.w * x.sw < (1L << 40) && x.n >= 1 && x.h >= 1 && x.w >= 1, "hg_bottleneck: extent");
     BneckK k;
     memset(&k, 0, sizeof(k));
@@ -378,7 +626,8 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     k.tiles_x = (k.W + 7) / 8; k.tiles_y = (k.H + 7) / 8;
     const long wgs = (long)k.B * k.tiles_x * k.tiles_y;
     FUSG_CHECK(wgs < (1L << 31), "hg_bottleneck: grid");
-    const void* fn = P == 128 ? (const void*)hg_bneck_h3<128> : (const void*)hg_bneck_h3<64>;
+    const void* fn = f32 ? (P == 128 ? (const void*)hg_bneck_f32<128> : (const void*)hg_bneck_f32<64>)
+                         : (P == 128 ? (const void*)hg_bneck_h3<128> : (const void*)hg_bneck_h3<64>);
     const size_t lds = bneck_lds(P) + TOUCH_LDS_BYTES;
     k.touch_w = env_switches().no_touch ? 0 : 1;
     if (hipError_t e = ensure_dyn_lds(fn, (int)lds); e != hipSuccess) { set_error("hg_bottleneck: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }

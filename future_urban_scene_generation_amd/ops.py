@@ -510,9 +510,10 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
 
 def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> bool:
     """Can this hourglass Bottleneck (packed plans c1, c2, c3 + bn1 affine) run as ONE launch (fusg_hg_bottleneck)?
-    planes 64 or 128, split-fp16 arithmetic, channels of x a multiple of 32.  FUSG_NO_BNECK=1 keeps the three launches;
-    FUSG_BNECK_MAXHW=n fuses only levels of at most n x n pixels."""
-    if (precision or PRECISION) != "f16x3" or _env_set("FUSG_NO_BNECK"):
+    planes 64 or 128, split-fp16 or (round 4) exact-fp32 arithmetic, channels of x a multiple of 32.  FUSG_NO_BNECK=1 keeps the
+    three launches (FUSG_NO_BNECK_F32=1: only for f32); FUSG_BNECK_MAXHW=n fuses only levels of at most n x n pixels."""
+    prec = precision or PRECISION
+    if prec not in ("f16x3", "f32") or _env_set("FUSG_NO_BNECK") or (prec == "f32" and (_env_set("FUSG_NO_BNECK_F32") or _env_set("FUSG_NO_F32_HALO"))):
         return False
     c1, c2, c3 = p["c1"], p["c2"], p["c3"]
     if not (c1.cout in (64, 128) and c2.cout == c1.cout and c3.cout == 2 * c1.cout and c1.kh == 1 and c2.kh == 3 and c3.kh == 1
@@ -521,18 +522,19 @@ def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> 
     lim = _os.environ.get("FUSG_BNECK_MAXHW")
     if lim is not None and max(x.shape[2], x.shape[3]) > int(lim):
         return False
-    # levels below BNECK_MINHW pixels a side run as three launches of the small-image kernel (csrc/conv_kernel_small.h): one
-    # workgroup per image walking 48 K-steps in series (25 us) against three ~5 us launches
+    # levels below BNECK_MINHW pixels a side run as three launches of the small-image kernel (csrc/conv_kernel_small.h): measured
+    # no faster than the fused block (profiles/r04_ab_experiments.txt), so BNECK_MINHW defaults to 0
     return max(x.shape[2], x.shape[3]) >= BNECK_MINHW or _env_set("FUSG_NO_SMALL")
 
 
 BNECK_MINHW = int(_os.environ.get("FUSG_BNECK_MINHW", "0"))
 
 
-def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None, precision: Optional[str] = None) -> torch.Tensor:
     """res + conv3(relu(conv2(relu(conv1(relu(bn1(x))))))) in one launch (fusg_hg_bottleneck; stacked_hourglass/
     models.py:22-42).  `p`: the packed Bottleneck (pre = bn1 scale / shift, c1 / c2 with bn2 / bn3 folded, c3);
-    `res` defaults to x (no downsample conv)."""
+    `res` defaults to x (no downsample conv).  precision "f32": the exact-fp32 form of the block (fp32 fragment copies)."""
+    f32 = (precision or PRECISION) == "f32"
     res = x if res is None else res
     b, _, h, w = x.shape
     planes = p["c1"].cout
@@ -543,15 +545,21 @@ def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> 
     if RECORDER is not None:
         RECORDER.keep.append(p["pre"])
     for i, key in ((1, "c1"), (2, "c2"), (3, "c3")):
-        dev = p[key].to(x.device).dev
+        plan = p[key].to(x.device)
+        dev = plan.dev
         if RECORDER is not None:
             RECORDER.keep.append(dev)
         assert dev.get("wfrag") is not None and dev["wfrag_order"] == 0, key
-        setattr(d, "w%dfrag" % i, dev["wfrag"].data_ptr())
+        frag = plan.frag_f32_dev() if f32 else dev["wfrag"]
+        assert frag is not None, key
+        if RECORDER is not None:
+            RECORDER.keep.append(frag)
+        setattr(d, "w%dfrag" % i, frag.data_ptr())
         setattr(d, "bias%d" % i, dev["bias"].data_ptr())
         setattr(d, "wscale%d" % i, dev["wscale"].data_ptr())
     d.status = status_word(x.device).data_ptr()
     d.planes = planes
+    d.exact_f32 = 1 if f32 else 0
     L.check(L.lib().fusg_hg_bottleneck(C.byref(d), stream_ptr()), "hg_bottleneck")
     return out
 

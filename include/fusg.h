@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 111
+#define FUSG_VERSION 112
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -240,7 +240,9 @@ typedef struct fusg_bneck_desc {
     const void*  w3frag; const float* bias3; const float* wscale3;     /* conv3: P -> 2 P, 1x1           */
     int32_t*     status;
     int32_t      planes;         /* P: 64 or 128 */
-    int32_t      _pad;
+    int32_t      exact_f32;      /* 0: split-fp16 (w*frag = the fusg_conv_desc.wfrag copies; wscale* and status required).
+                                    1 (round 4): exact fp32 on v_mfma_f32_16x16x4_f32 - w*frag = the fusg_conv_desc.wfrag_f32
+                                    copies (pack.py: frag_f32), wscale* and status unused */
 } fusg_bneck_desc;
 int fusg_hg_bottleneck(const fusg_bneck_desc* d, void* stream);
 

@@ -700,10 +700,10 @@ def _bneck_ref(x, res, prm):
     return F.conv2d(t, w3, b3) + res.double()
 
 
-def _bneck_unfused(p, x, res):
-    t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU, precision="f16x3")
-    t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision="f16x3")
-    return ops.conv(p["c3"], t, res0=res, precision="f16x3")
+def _bneck_unfused(p, x, res, precision="f16x3"):
+    t = ops.conv(p["c1"], x, pre_op=L.PRE_AFFINE_RELU, pre=p["pre"], act=L.ACT_RELU, precision=precision)
+    t = ops.conv(p["c2"], t, act=L.ACT_RELU, precision=precision)
+    return ops.conv(p["c3"], t, res0=res, precision=precision)
 
 
 @pytest.mark.parametrize("B,cin,H,W,own_res,planes", [(2, 256, 8, 8, False, 128), (3, 256, 4, 4, False, 128),
@@ -715,8 +715,6 @@ def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision):
     """One-launch Bottleneck against an fp64 reference and against the three launches it replaces (same arithmetic,
     different summation order): error relative to the output's largest magnitude <= 2e-6 (observed ~3e-7), and no
     worse than 2x the three-launch path's."""
-    if precision != "f16x3":
-        pytest.skip("the fused block exists on the split-fp16 path only")
     from conftest import record
     p, prm = _bneck_params(cin, seed=21, planes=planes)
     x = _rand(B, cin, H, W, seed=22)
@@ -726,10 +724,10 @@ def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision):
     xin = _nhwc(x)
     rin = _nhwc(res) if own_res else xin
     assert ops.bottleneck_ok(p, xin)
-    got = ops.bottleneck(p, xin, rin)
+    got = ops.bottleneck(p, xin, rin)                   # (f32: the exact-fp32 form of the block, round 4)
     assert ops.last_conv_kernel() == 6
     assert not ops.range_exceeded(dev())
-    un = _bneck_unfused(p, xin, rin)
+    un = _bneck_unfused(p, xin, rin, precision)
     den = float(ref.abs().max())
     e_f = float((got.cpu().double() - ref).abs().max()) / den
     e_u = float((un.cpu().double() - ref).abs().max()) / den
@@ -767,8 +765,6 @@ def test_hg_bottleneck_fused_range_and_scale(precision):
 def test_hg_bottleneck_fused_random_shapes(precision):
     """Seeded sweep over image sizes that do not divide into 8 x 8 patches, batch sizes and input widths: the fused
     block equals the three launches to 1e-6 of the output's range everywhere (same arithmetic, different order)."""
-    if precision != "f16x3":
-        pytest.skip("split-fp16 path only")
     rng = np.random.default_rng(5)
     for it in range(16):
         cin = int(rng.choice([32, 64, 128, 256, 288]))
@@ -779,7 +775,7 @@ def test_hg_bottleneck_fused_random_shapes(precision):
         res = _rand(B, 2 * planes, H, W, seed=300 + it)
         xin, rin = _nhwc(x), _nhwc(res)
         got = ops.bottleneck(p, xin, rin)
-        un = _bneck_unfused(p, xin, rin)
+        un = _bneck_unfused(p, xin, rin, precision)
         err = float((got - un).abs().max() / un.abs().max())
         assert err < 1e-6, (cin, B, H, W, err)
     assert not ops.range_exceeded(dev())
@@ -789,8 +785,6 @@ def test_hg_bottleneck_fused_is_deterministic(precision):
     """Race check of the fused block's LDS hand-offs (conv1 -> T -> conv2 -> U -> conv3, T and U overlaid): 100 launches
     on a grid that fills the chip several times over, interleaved with a kernel that dirties LDS-sized state, must give
     bit-identical outputs."""
-    if precision != "f16x3":
-        pytest.skip("split-fp16 path only")
     for planes, cin, hw in ((128, 256, 64), (64, 64, 96)):
         p, _ = _bneck_params(cin, seed=41, planes=planes)
         x = _nhwc(_rand(8, cin, hw, hw, seed=42))
