@@ -29,7 +29,7 @@ namespace fusg {
 
 constexpr int SMALL_NS = 9;            // weight steps a wave holds in registers at once (4 fragments of 4 VGPRs each)
 constexpr int SMALL_ROWS = 32;         // output rows per workgroup
-constexpr int SMALL_MAXPIX = 160;      // staged input pixels per workgroup (host-checked)
+constexpr int SMALL_MAXPIX = 192;      // staged input pixels per workgroup (host-checked; one thread per pixel fills the source table)
 
 struct SmallK {
     ConvK c;

@@ -103,5 +103,72 @@ def main():
     print(f"sum over the pass's counts: small {tot['small'] / 1e3:.3f} ms, replaced {tot['old'] / 1e3:.3f} ms per pass ")
 
 
+def ring():
+    """The twelve ring launches of one ICN up-convolution (pack.pack_conv_up2_ring), each timed alone: small-image kernel vs the
+    generic gather (FUSG_NO_SMALL=1), and the four 25-tap windows they replace."""
+    from future_urban_scene_generation_amd.pack import up2_ring_launches
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    dev = torch.device("cuda:0")
+    ops.set_precision("f16x3")
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, h in ((256, 128, 64), (128, 64, 128)):
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+        bvec = torch.zeros(cout)
+        rg = {k: v.to(dev) for k, v in pack.pack_conv_up2_ring(w, bvec).items()}
+        exact = pack.pack_conv(w, bvec, pad=2, pad_mode=1, upsample=1).to(dev)
+        x = ops.as_nhwc(torch.randn(B, cin, h, h, generator=g).to(dev))
+        sc = torch.rand(B, cin, generator=g).to(dev) + 0.5
+        sh = torch.randn(B, cin, generator=g).to(dev) * 0.2
+        out = ops.nhwc_empty(B, cout, 2 * h, 2 * h, dev)
+        kw = dict(pre_op=L.PRE_AFFINE_RELU, pre=(sc, sh), pre_bstride=cin)
+
+        def timed(fn, n=50):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            rec = ops.PlanRecorder()
+            L.check(L.lib().fusg_plan_begin(rec.handle), "plan_begin")
+            ops.RECORDER = rec
+            try:
+                for _ in range(n):
+                    fn()
+            finally:
+                ops.RECORDER = None
+                L.check(L.lib().fusg_plan_end(rec.handle), "plan_end")
+            torch.cuda.synchronize()
+            L.check(L.lib().fusg_plan_run(rec.handle), "plan_run")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                L.check(L.lib().fusg_plan_run(rec.handle), "plan_run")
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / (3 * n) * 1e6
+            L.lib().fusg_plan_destroy(rec.handle)
+            return us
+
+        print(f"ring of {cin}->{cout} k5 up2 at {h}x{h}, B={B}:  us per launch  small / generic")
+        tot = [0.0, 0.0]
+        for ry, rx, win, off in up2_ring_launches(h, h):
+            res = []
+            for arm in ("small", "old"):
+                if arm == "old":
+                    os.environ["FUSG_NO_SMALL"] = "1"
+                else:
+                    os.environ.pop("FUSG_NO_SMALL", None)
+                res.append(timed(lambda: ops.conv(rg[(ry, rx)], x, out=out, q_window=win, out_stride=2, out_off=off, **kw)))
+                res.append(ops.last_conv_kernel())
+            os.environ.pop("FUSG_NO_SMALL", None)
+            tot[0] += res[0]
+            tot[1] += res[2]
+            print(f"   kind {ry}{rx} window {win}  {res[0]:7.1f} / {res[2]:7.1f}   kernel {res[1]}/{res[3]}", flush=True)
+        t25 = 0.0
+        for win in ((0, 0, 1, 2 * h), (2 * h - 1, 0, 1, 2 * h), (0, 0, 2 * h, 1), (0, 2 * h - 1, 2 * h, 1)):
+            t25 += timed(lambda: ops.conv(exact, x, out=out, q_window=win, **kw))
+        print(f"   twelve launches: small {tot[0]:.1f} us, generic {tot[1]:.1f} us;  the four 25-tap windows: {t25:.1f} us")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ring":
+        ring()
+    else:
+        main()
