@@ -170,3 +170,31 @@ def test_slice_scene_partitions_the_vehicles():
         assert sub["src_kp"] == [[v] for v in range(lo, hi)] and sub["masks"][:, 0, 0].tolist() == list(range(lo, hi))
     assert seen == list(range(V))
     assert len(scene["bboxes"]) == V                                           # the caller's dict is untouched
+
+
+def test_later_frame_scenes_shard_like_first_frames():
+    """Round 4 (a clip sharded over ranks): a later frame's scene has no detector boxes or CAD keypoints - `slice_scene` cuts what
+    is there at the same bounds - and `synth_later_frame` keeps the vehicles (masks, first-frame planes) while giving every
+    (vehicle, trajectory step) its own noise seed, so a vehicle's images do not depend on the rank that renders its clip."""
+    import numpy as np
+    from future_urban_scene_generation_amd.pipeline import slice_scene, synth_later_frame
+    V = 5
+    first = {"frame": torch.zeros(4, 6, 3, dtype=torch.uint8), "masks": torch.arange(V).view(V, 1, 1).expand(V, 4, 6),
+             "src_sketch": torch.ones(V, 4, 6, 3), "dst_sketch": torch.zeros(V, 4, 6, 3), "src_planes": torch.zeros(V, 5, 4, 6, 3),
+             "src_kp": [[np.full((4, 2), v, np.int32)] * 5 for v in range(V)], "dst_kp": [[np.zeros((4, 2), np.int32)] * 5 for v in range(V)],
+             "src_vis": np.ones((V, 5)), "dst_vis": np.ones((V, 5)), "vehicle_seeds": [10 + v for v in range(V)],
+             "bboxes": np.zeros((V, 4)), "kp3d": np.zeros((V, 12, 3))}
+    later = synth_later_frame(first, 3)
+    assert later["masks"] is first["masks"] and later["src_planes"] is first["src_planes"] and later["src_kp"] is first["src_kp"]
+    assert later["dst_sketch"] is first["src_sketch"]
+    assert later["vehicle_seeds"] == [(10 + v) * 64 + 3 for v in range(V)] and first["vehicle_seeds"] == [10 + v for v in range(V)]
+    assert all(d.shape == s.shape and d.dtype == np.int32 for dv, sv in zip(later["dst_kp"], first["src_kp"]) for d, s in zip(dv, sv))
+    assert synth_later_frame(first, 3)["dst_kp"][2][1].tolist() == later["dst_kp"][2][1].tolist()       # seeded by the step
+    later = {k: v for k, v in later.items() if k not in ("bboxes", "kp3d")}      # what a real later frame carries
+    seen = []
+    for r in range(2):
+        lo, hi = shard_range(V, r, 2)
+        sub = slice_scene(later, lo, hi)
+        assert "bboxes" not in sub and sub["masks"][:, 0, 0].tolist() == list(range(lo, hi)) and len(sub["dst_kp"]) == hi - lo
+        seen += sub["vehicle_seeds"]
+    assert seen == later["vehicle_seeds"]

@@ -288,3 +288,25 @@ def test_up2_ring_weights_reproduce_the_reflect_padded_5x5_on_the_outermost_ring
     assert torch.equal(cnt, ring.float())
     assert float((out[:, :, ring] - ref[:, :, ring]).abs().max()) < 1e-12
     assert sorted(pack.pack_conv_up2_ring(w.float(), None)) == sorted({(a, b) for a, b, _, _ in pack.up2_ring_launches(H, W)})
+
+
+def test_frag_f32_is_the_lane_order_of_the_fp32_matrix_instruction():
+    """fusg_conv_desc.wfrag_f32 (exact-fp32 halo kernel / fused Bottleneck, round 4): [tap][chunk][cout_pad/32][16-column half][h]
+    [lane][4] with lane = g * 16 + column holding w[column][32 chunk + 16 h + 4 g + e] - what lane (column, g) feeds
+    v_mfma_f32_16x16x4_f32 number (h, e) of a 32-channel chunk; stride-2 layers reorder the tap slabs like the fp16 copy."""
+    import torch
+    from future_urban_scene_generation_amd import pack
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(40, 96, 3, 3, generator=g)
+    plan = pack.pack_conv(w, None, c_split=(32, 64), pad=1)
+    f = pack.frag_f32(plan.wpack, plan)
+    assert tuple(f.shape) == (9, 3, 2, 2, 2, 64, 4) and f.dtype == torch.float32
+    for tap, chunk, nt, ct, h, lane, e in ((0, 0, 0, 0, 0, 0, 0), (4, 2, 1, 1, 1, 37, 3), (8, 1, 0, 1, 0, 63, 2), (5, 0, 1, 0, 1, 16, 1)):
+        gq, col = lane >> 4, lane & 15
+        n = nt * 32 + ct * 16 + col
+        k = tap * 96 + chunk * 32 + 16 * h + 4 * gq + e
+        assert float(f[tap, chunk, nt, ct, h, lane, e]) == float(plan.wpack[0, n, k])
+    assert float(f[4, 2, 1, 1, 1, 37, 3]) == 0.0                                  # column 61 >= cout 40: zero padding
+    s2 = pack.pack_conv(torch.randn(32, 32, 3, 3, generator=g), None, stride=2, pad=1)
+    assert s2.s2d_ok() and pack.frag_f32(s2.wpack, s2) is not None
+    assert pack.frag_f32(pack.pack_conv(torch.randn(8, 3, 7, 7, generator=g), None, pad=3).wpack, pack.pack_conv(torch.randn(8, 3, 7, 7, generator=g), None, pad=3)) is None
