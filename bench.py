@@ -278,7 +278,7 @@ def cpu_baseline_leg(args, batch, pipe, torch):
     return base, quality
 
 
-def vunet_forward_leg(args, pipe, torch, with_cpu=True):
+def vunet_forward_leg(args, pipe, torch, with_cpu=True, threads=None):
     """BASELINE configs[0] ("single 256x256 crop, vunet.models forward only, --device cpu"): the latency of ONE
     `Vunet_fix_res.forward(y_tilde, x)` call at batch 1 - the drop-in module called eagerly (what run_test.py would do),
     the pipeline's form of the same call (shape encoder on its side stream) eagerly and as a recorded-plan replay -
@@ -315,6 +315,9 @@ def vunet_forward_leg(args, pipe, torch, with_cpu=True):
     if with_cpu:
         sd = synth_state_dict("vunet", load_schema("vunet"), 0)
         y, x = b1["vu_y"].cpu(), b1["vu_x"].cpu()
+        default_threads = torch.get_num_threads()
+        if threads:
+            torch.set_num_threads(int(threads))              # the count the cpu_baseline sweep found best on this host
         oracle.vunet_forward(sd, y, x)
         best = None
         for _ in range(3):
@@ -327,6 +330,7 @@ def vunet_forward_leg(args, pipe, torch, with_cpu=True):
         got = pipe.vunet_forward(b1)["vunet_u8"].cpu().numpy()
         out["cpu_port_ms"] = round(best * 1e3, 1)
         out["cpu_threads"] = torch.get_num_threads()
+        torch.set_num_threads(default_threads)
         out["ssim_vs_cpu_ref"] = round(float(oracle.ssim(got, oracle.to_image_u8(ref))), 6)
     return out
 
@@ -662,7 +666,8 @@ def main():
         cpu_baseline, quality = cpu_baseline_leg(args, batch, pipe, torch)
         extra.update(quality)
     if rank == 0 and world == 1 and not args.no_clip and not args.inpaint and args.res == 256:
-        extra["configs0_vunet_forward_b1"] = vunet_forward_leg(args, pipe, torch, with_cpu=not args.no_cpu_baseline)
+        extra["configs0_vunet_forward_b1"] = vunet_forward_leg(args, pipe, torch, with_cpu=not args.no_cpu_baseline,
+                                                               threads=cpu_baseline["cores"] if cpu_baseline else None)
 
     if rank == 0:
         h = legs[head]

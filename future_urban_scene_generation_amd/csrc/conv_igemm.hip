@@ -193,7 +193,7 @@ static bool small_cfg(const fusg_conv_desc* d, int precision, SmallCfg* out) {
         c.mt = B * c.tpi;
     }
     c.NPIX = c.nimg * c.RIN * c.WIN;
-    if (c.NPIX > SMALL_MAXPIX) return false;
+    if (c.NPIX > SMALL_MAXPIX || c.mt * c.tpi >= (1L << 31) || c.mt * (d->cout_pad / 32) >= (1L << 31) || (long)hw * c.tpi >= (1L << 16)) return false;
     c.nch32 = ctot / 32; c.ntaps = ntaps;
     // chunks per K range: the staged image must fit (<= 112 KiB) and a wave should not need more than two rounds of weights
     int nchw = (112 * 1024) / (c.NPIX * 128);
@@ -458,9 +458,11 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             h.RIN = sc.RIN; h.WIN = sc.WIN; h.NPIX = sc.NPIX;
             auto magic = [](int dv) -> unsigned { return dv < 2 ? 0u : (unsigned)(((1UL << 32) + (unsigned long)dv - 1) / (unsigned long)dv); };
             h.m_wo = magic(d->qw); h.m_hw = magic(d->qh * d->qw); h.m_win = magic(sc.WIN); h.m_rw = magic(sc.RIN * sc.WIN);
-            h.m_npix = magic(sc.NPIX); h.m_taps = magic(sc.ntaps); h.m_ihw = magic((int)(x0.h * x0.w)); h.m_tpi = magic(sc.tpi);
-            // (the reciprocals are exact while dividend * divisor < 2^32: the largest dividend is a source pixel index)
-            if ((long)x0.n * x0.h * x0.w * (x0.h * x0.w) < (1L << 32) && Ml * (long)(d->qh * d->qw) < (1L << 32)) {
+            h.m_npix = magic(sc.NPIX); h.m_taps = magic(sc.ntaps); h.m_tpi = magic(sc.tpi);
+            // (the reciprocals are exact while dividend * divisor < 2^32: the dividends are tile indices (< 2^31 / tpi, checked in
+            // small_cfg), pixel indices inside a 32-row tile and step numbers - the planner and this launcher must agree, or a
+            // layer planned for this kernel would run on the generic gather with this kernel's tile / split choice)
+            {
                 h.c.MT = (int)sc.mt; h.c.NT = d->cout_pad / 32;
                 h.c.ksplit = sc.ksplit;
                 dim3 sgrid(h.c.MT * h.c.NT, 1, sc.ksplit);

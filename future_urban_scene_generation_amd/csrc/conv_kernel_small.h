@@ -50,7 +50,7 @@ struct SmallK {
     int pad_mode;               // FUSG_PAD_ZERO or FUSG_PAD_REPLICATE (clamped coordinates: the ring windows of the ICN's up-convolutions)
     int RIN, WIN, NPIX;         // staged region per image (rows, columns), pixels in all = nimg * RIN * WIN
     int rpi_shift;              // log2(rpi)
-    unsigned m_wo, m_hw, m_win, m_rw, m_npix, m_taps, m_ihw, m_tpi;   // reciprocals (sdiv) of Wo, Ho*Wo, WIN, RIN*WIN, NPIX, ntaps, H*W, tpi
+    unsigned m_wo, m_hw, m_win, m_rw, m_npix, m_taps, m_tpi;   // reciprocals (sdiv) of Wo, Ho*Wo, WIN, RIN*WIN, NPIX, ntaps, tpi: every dividend is < 2^16
     int part_off;               // byte offset of the partial tiles in dynamic LDS
 };
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
         constexpr int UN = 4;
         for (int it0 = t; it0 < nitems; it0 += 256 * UN) {
             f32x4 v[UN];
-            int lo_[UN], srcp[UN], cidx[UN];
+            int lo_[UN], srcp[UN], cidx[UN], pxs[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int it = it0 + 256 * u;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
                     const bool s1 = cg >= sk.nch0;
                     const int sp = pixsrc[px];
                     srcp[u] = sp;
+                    pxs[u] = px;
                     cidx[u] = (s1 ? p.C0 + (cg - sk.nch0) * 32 : cg * 32) + kc * 4;
                     const float* base = s1 ? p.src1 + (long)max(sp, 0) * p.Cs1 + (cg - sk.nch0) * 32 + kc * 4
                                            : p.src0 + (long)max(sp, 0) * p.Cs0 + cg * 32 + kc * 4;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[c] = elu1(x[c]);
                 } else if (PK == PK_AFFINE) {
-                    const int b = srcp[u] >= 0 ? sdiv(srcp[u], sk.m_ihw) : 0;
+                    const int b = min(b0 + sdiv(pxs[u], sk.m_rw), p.B - 1);       // the staged pixel's image (no division by H * W)
                     const f32x4 sc = *(const f32x4*)(p.pre_scale + (long)b * p.pre_bstride + cidx[u]);
                     const f32x4 sh = *(const f32x4*)(p.pre_shift + (long)b * p.pre_bstride + cidx[u]);
                     const bool ok = srcp[u] >= 0;
