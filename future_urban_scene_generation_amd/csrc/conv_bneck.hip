@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float y = fmaxf(fmaf(acc1[i][j][r], wsc[r], bias[r]), 0.f); v[r] = ok ? y : 0.f; }
                 h4 hi, lo;
-                split4(v, ninf, hi, lo, amax);
+                split4<false>(v, ninf, hi, lo, amax);
                 if (pix < BN_HP) {
                     const int o = ((gct >> 1) * BN_HP + pix) * 32 + ((g ^ ((hy & 1) << 1)) << 3) + sub;
                     *(h4*)(Th + o) = hi;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc2[i][j][r], wsc[r], bias[r]), 0.f);
                 h4 hi, lo;
-                split4(v, ninf, hi, lo, amax);
+                split4<false>(v, ninf, hi, lo, amax);
                 const int o = ((gct >> 1) * 64 + i * 16 + lp) * 32 + ((g ^ (((lp >> 2) & 1) << 1)) << 3) + sub;
                 *(h4*)(Uh + o) = hi;
                 *(h4*)(Ul + o) = lo;

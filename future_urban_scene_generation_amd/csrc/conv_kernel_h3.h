@@ -48,9 +48,14 @@ constexpr float F16X3_LIMIT = 32768.f;   // |a| >= 2^15: outside the split's ran
 // hi straight from its fp16 half, computes hi * -2^11 + a * 2^11 exactly in fp32 and rounds once to fp16
 // (hipcc has no pattern for it: inline asm); amax: v_max3_f32 with |.| source modifiers.  3 VALU ops per
 // element + 1 for the floor.
+// FLOOR = false: no clamp at all (the ELU pre-op and the fused Bottleneck's intermediates have none: the four v_max against -inf
+// were 9 % of the staging VALU work of an ELU layer, which is what bounds the 32 / 64-column launches - DESIGN.md §9).
+template <bool FLOOR = true>
 __device__ __forceinline__ void split4(f32x4 v, float floor, h4& hi, h4& lo, float& amax) {
+    if constexpr (FLOOR) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], floor);
+        for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], floor);
+    }
     const h2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
     const unsigned p01 = __builtin_bit_cast(unsigned, h01), p23 = __builtin_bit_cast(unsigned, h23);
     const float m2048 = -2048.f;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(const ConvK p) {
                 for (int c = 0; c < 4; ++c) v[c] = ok ? v[c] : 0.f;
             }
             h4 hi, lo;
-            split4(v, vfloor, hi, lo, amax);
+            if constexpr (PK == PK_ELU) split4<false>(v, vfloor, hi, lo, amax); else split4(v, vfloor, hi, lo, amax);
             *(h4*)(ah + 32 * i * LDH) = hi;
             *(h4*)(al + 32 * i * LDH) = lo;
         }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                 if ((hexist >> j) & 1u) *(bf4*)(Ah + hoff[j]) = hb;
             } else {
                 h4 hi, lo;
-                split4(v, vfloor, hi, lo, amax);
+                if constexpr (PK == PK_ELU) split4<false>(v, vfloor, hi, lo, amax); else split4(v, vfloor, hi, lo, amax);
                 if ((hexist >> j) & 1u) {
                     *(h4*)(Ah + hoff[j]) = hi;
                     *(h4*)(Al + hoff[j]) = lo;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void conv_small_h3(const SmallK sk) {
                     for (int c = 0; c < 4; ++c) { const float y = fmaf(x[c], sc[c], sh[c]); x[c] = ok ? y : 0.f; }
                 }
                 h4 hi, lo;
-                split4(x, vfloor, hi, lo, amax);
+                if constexpr (PK == PK_ELU) split4<false>(x, vfloor, hi, lo, amax); else split4(x, vfloor, hi, lo, amax);
                 *(h4*)(Ah + lo_[u]) = hi;
                 *(h4*)(Al + lo_[u]) = lo;
             }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
             h4 hi, lo;
-            split4(v, vfloor, hi, lo, amax);
+            if constexpr (PK == PK_ELU) split4<false>(v, vfloor, hi, lo, amax); else split4(v, vfloor, hi, lo, amax);
             *(h4*)(Ah + hoff[j]) = hi;
             *(h4*)(Al + hoff[j]) = lo;
         }

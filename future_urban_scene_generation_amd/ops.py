@@ -522,12 +522,16 @@ def bottleneck_ok(p: dict, x: torch.Tensor, precision: Optional[str] = None) -> 
     lim = _os.environ.get("FUSG_BNECK_MAXHW")
     if lim is not None and max(x.shape[2], x.shape[3]) > int(lim):
         return False
-    # levels below BNECK_MINHW pixels a side run as three launches of the small-image kernel (csrc/conv_kernel_small.h): measured
-    # no faster than the fused block (profiles/r04_ab_experiments.txt), so BNECK_MINHW defaults to 0
-    return max(x.shape[2], x.shape[3]) >= BNECK_MINHW or _env_set("FUSG_NO_SMALL")
+    # Levels below a minimum size run as three launches (small-image kernel at 4 x 4 / 8 x 8, halo kernel at 16 x 16) instead of the
+    # fused block, whose grid there is one workgroup per image walking 48 K-steps in series.  Measured (profiles/
+    # r04_ab_experiments.txt [r04j], recorded-plan replay): with at most 8 images the three launches win - B = 8 1266 -> 1305
+    # crops/s, B = 1 2.10 -> 2.03 ms per pass with levels < 32 unfused - from B = 16 up the fused block wins (B = 32: conv 23.5 ->
+    # 23.8 ms).  FUSG_BNECK_MINHW=n overrides (0 = always fused).
+    minhw = BNECK_MINHW if BNECK_MINHW is not None else (32 if x.shape[0] <= 8 and prec == "f16x3" else 0)
+    return max(x.shape[2], x.shape[3]) >= minhw or _env_set("FUSG_NO_SMALL")
 
 
-BNECK_MINHW = int(_os.environ.get("FUSG_BNECK_MINHW", "0"))
+BNECK_MINHW = int(_os.environ["FUSG_BNECK_MINHW"]) if "FUSG_BNECK_MINHW" in _os.environ else None
 
 
 def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None, precision: Optional[str] = None) -> torch.Tensor:
