@@ -711,7 +711,7 @@ def _bneck_unfused(p, x, res, precision="f16x3"):
                                                         (2, 128, 32, 32, True, 128), (1, 256, 12, 20, False, 128),
                                                         (2, 64, 5, 9, True, 128), (2, 64, 32, 32, True, 64),
                                                         (1, 128, 16, 24, False, 64), (1, 64, 128, 128, True, 64)])
-def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision):
+def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision, monkeypatch):
     """One-launch Bottleneck against an fp64 reference and against the three launches it replaces (same arithmetic,
     different summation order): error relative to the output's largest magnitude <= 2e-6 (observed ~3e-7), and no
     worse than 2x the three-launch path's."""
@@ -723,7 +723,10 @@ def test_hg_bottleneck_fused(B, cin, H, W, own_res, planes, precision):
     ref = _bneck_ref(x, res, prm)
     xin = _nhwc(x)
     rin = _nhwc(res) if own_res else xin
+    monkeypatch.setattr(ops, "BNECK_MINHW", 0)          # (by default small batches run the low levels as three launches: ops.bottleneck_ok)
     assert ops.bottleneck_ok(p, xin)
+    monkeypatch.setattr(ops, "BNECK_MINHW", None)
+    assert ops.bottleneck_ok(p, xin) == (precision == "f32" or B > 8 or max(H, W) >= 32)
     got = ops.bottleneck(p, xin, rin)                   # (f32: the exact-fp32 form of the block, round 4)
     assert ops.last_conv_kernel() == 6
     assert not ops.range_exceeded(dev())

@@ -23,6 +23,10 @@ cd /tmp && export TMPDIR=/tmp
 FUSG_STREAMS=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 $R/bench.py --steps 10 --warmup 5 --precision f16x3 --no-cpu-baseline --no-clip > $out/stats.log 2>&1
 grep '^{"metric"' $out/stats.log > $out/${tag}_bench_cfg1_serial_under_rocprof.json
 cp $(ls $out/stats/*/*_kernel_stats.csv | head -1) $out/${tag}_bench_cfg1_kernel_stats.csv
+# the exact-fp32 leg (round 4: halo kernel mode 2, fused Bottleneck in fp32)
+FUSG_STREAMS=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats32 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 3 --precision f32 --no-cpu-baseline --no-clip > $out/stats32.log 2>&1
+grep '^{"metric"' $out/stats32.log > $out/${tag}_bench_f32_serial_under_rocprof.json
+cp $(ls $out/stats32/*/*_kernel_stats.csv | head -1) $out/${tag}_bench_f32_kernel_stats.csv
 echo "rocprof stats done"
 # HBM traffic: separate PMC passes (FETCH_SIZE, WRITE_SIZE)
 FUSG_STREAMS=0 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --precision f16x3 --no-cpu-baseline --no-clip --no-prof > $out/pmc_f.log 2>&1
@@ -37,6 +41,8 @@ echo "pmc done"
 timeout -k 10 200 python tools/bneck_exp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_bneck_fused_vs_3_launches.txt
 timeout -k 10 200 python tools/issue_time.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_replay_issue_vs_done.jsonl
 FUSG_STREAMS=0 timeout -k 10 300 python tools/layer_profile.py --top 90 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile.txt
+FUSG_STREAMS=0 FUSG_PRECISION=f32 timeout -k 10 300 python tools/layer_profile.py --top 60 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile_f32.txt
+timeout -k 10 300 python tools/small_exp.py 32 2>&1 | grep -v amdgpu.ids > $out/${tag}_small_image_kernel_per_layer.txt
 timeout -k 10 400 python tools/halo_exp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_halo_layers_sustained.txt
-rm -rf $out/stats $out/pmc_f $out/pmc_w $out/pmc_m
+rm -rf $out/stats $out/stats32 $out/pmc_f $out/pmc_w $out/pmc_m
 echo "all done"
