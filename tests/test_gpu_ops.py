@@ -951,6 +951,7 @@ def test_f32_halo_kernel(B, c0, c1, cout, k, stride, pad, dil, pm, H, W, pre, pr
     xp = F.pad(xin.double(), (pad,) * 4, mode="reflect") if pm else xin.double()
     ref = F.conv2d(xp, w.double(), b.double(), stride=stride, padding=0 if pm else pad, dilation=dil)
     a0, a1 = _nhwc(x0), (_nhwc(x1) if c1 else None)
+    kw["ksplit"] = 1                              # (K whole: a grid this small would otherwise take the generic gather with split-K)
     got = ops.conv(plan, a0, a1, **kw)
     assert ops.last_conv_kernel() == 9, ops.last_conv_kernel()
     os.environ["FUSG_NO_F32_HALO"] = "1"

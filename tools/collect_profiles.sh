@@ -43,6 +43,7 @@ timeout -k 10 200 python tools/issue_time.py 2>&1 | grep -v amdgpu.ids > $out/${
 FUSG_STREAMS=0 timeout -k 10 300 python tools/layer_profile.py --top 90 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile.txt
 FUSG_STREAMS=0 FUSG_PRECISION=f32 timeout -k 10 300 python tools/layer_profile.py --top 60 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile_f32.txt
 timeout -k 10 300 python tools/small_exp.py 32 2>&1 | grep -v amdgpu.ids > $out/${tag}_small_image_kernel_per_layer.txt
+FUSG_STREAMS=0 timeout -k 10 300 python tools/layer_profile.py --batch 1 --top 40 2>&1 | grep -v amdgpu.ids > $out/${tag}_layer_profile_b1.txt
 timeout -k 10 400 python tools/halo_exp.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_halo_layers_sustained.txt
 rm -rf $out/stats $out/stats32 $out/pmc_f $out/pmc_w $out/pmc_m
 echo "all done"
