@@ -765,7 +765,7 @@ class VehiclePipeline:
         return out
 
     # ------------------------------------------------------------------------------------------ future frames of a clip
-    def run_later_frame(self, scene: Dict, state: Dict, check: Optional[str] = "sync") -> Dict:
+    def run_later_frame(self, scene: Dict, state: Dict, check: Optional[str] = "sync", replay: bool = False) -> Dict:
         """A FUTURE frame of vehicles whose first frame `run_frame` rendered (trajectory_inference.py:283-450, per vehicle and
         trajectory step): no hourglass, no pose fit, no appearance encoder - the source planes warped to the new pose -> ICN
         inputs (with the first frame's central crop) -> ICN -> Lab image (:376-391); the new sketch -> VUnet shape encoder ->
@@ -775,6 +775,8 @@ class VehiclePipeline:
         'masks', 'dst_sketch', 'dst_kp', 'dst_vis' of the new pose, 'src_planes' / 'src_kp' / 'src_vis' of the first frame,
         optional 'vehicle_seeds' (the shape decoder draws its sampler noise: a seed per vehicle and frame keeps a vehicle's
         images independent of batching); state: `run_frame(...)["state"]` of the same vehicles, same order.
+        replay=True issues the two networks (ICN, VUnet shape half) as ONE recorded-plan replay per vehicle count, like
+        `run_frame(replay=True)`: five of a clip's six frames are later frames, and at 8 vehicles the interpreter bounds the eager form.
         Returns 'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom'."""
         rng = torch.get_rng_state() if (check == "sync" and scene.get("vehicle_seeds") is None) else None
         import torch.distributed as dist
@@ -787,16 +789,34 @@ class VehiclePipeline:
             lo, hi, V = state["shard"]
             if int(scene["masks"].shape[0]) != V:
                 raise ValueError(f"run_later_frame: the state was made for a frame of {V} vehicles, the scene holds {int(scene['masks'].shape[0])}")
-            local = self._guarded(self._later_local, (slice_scene(scene, lo, hi), state), check, rng)
+            local = self._guarded(self._later_local, (slice_scene(scene, lo, hi), state, replay), check, rng)
             full = self._gather_local(local, V, False)
             return None if full is None else self._later_finish(scene, full)
-        return self._guarded(self._run_later_frame, (scene, state), check, rng)
+        return self._guarded(self._run_later_frame, (scene, state, replay), check, rng)
 
-    def _run_later_frame(self, scene, state):
-        return self._later_finish(scene, self._later_local(scene, state))
+    def _run_later_frame(self, scene, state, replay=False):
+        return self._later_finish(scene, self._later_local(scene, state, replay))
 
     @torch.no_grad()
-    def _later_local(self, scene, state):
+    def _later_nets(self, batch, vehicle_seeds=None):
+        """The two networks of a later frame (trajectory_inference.py:389, :424-426) as a pass function (`CompiledPass(fn=...)`):
+        batch = 'icn_x' [V, 21, R, R], 'vu_y' [V, 3, R, R], 'app0' / 'app1' = the first frame's appearance code."""
+        from . import ops
+        self.vunet.set_vehicle_seeds(vehicle_seeds)
+
+        def icn():
+            return {"icn_u8": ops.to_image_u8(self.icn(batch["icn_x"]))}                   # :389
+
+        def vunet():
+            vu = self.vunet
+            do, ds = vu.forward_dec_up(batch["vu_y"])                                      # :424
+            xt, _, _ = vu.forward_dec_down(do, ds, [batch["app0"], batch["app1"]])         # :425
+            return {"vunet_u8": ops.to_image_u8(xt)}                                       # :426
+
+        return self._branches([("icn", icn), ("vunet", vunet)])
+
+    @torch.no_grad()
+    def _later_local(self, scene, state, replay=False):
         """The per-vehicle part of a later frame for the vehicles `scene` lists (all, or one rank's shard - `state` holds
         exactly these vehicles): warp, ICN, VUnet shape half.  Returns 'icn_u8' (BGR), 'vunet_u8', 'geom'."""
         from . import frame_ops as fo
@@ -817,18 +837,25 @@ class VehiclePipeline:
             _, geom = fo.mask_bbox_geom(scene["masks"])
             icn_x = pu.icn_inputs_device(warped, scene["dst_sketch"], state["central"], geom, R, R)   # :385-387
             _, vu_y = fo.vunet_inputs(frame, scene["masks"], scene["dst_sketch"], scene["dst_sketch"], geom, R)   # :415-420 (y_tilde only)
-            self.vunet.set_vehicle_seeds(scene.get("vehicle_seeds"))
-
-            def icn():
-                return {"icn_u8": ops.to_image_u8(self.icn(icn_x))}                            # :389
-
-            def vunet():
-                vu = self.vunet
-                do, ds = vu.forward_dec_up(vu_y)                                               # :424
-                xt, _, _ = vu.forward_dec_down(do, ds, list(state["appearance"]))              # :425
-                return {"vunet_u8": ops.to_image_u8(xt)}                                       # :426
-
-            out = self._branches([("icn", icn), ("vunet", vunet)])
+            seeds = scene.get("vehicle_seeds")
+            nets_in = {"icn_x": icn_x, "vu_y": vu_y, "app0": state["appearance"][0], "app1": state["appearance"][1]}
+            replay = replay and ops.RECORDER is None
+            if replay:
+                cps = self.__dict__.setdefault("_frame_plans", {})
+                key = ("later", V, ops.PRECISION)
+                cp = cps.get(key)
+                if cp is not None and [n.generation for n in self._nets] != cp.generations:
+                    cp = None
+                if cp is None:
+                    cps.pop(key, None)
+                    while len(cps) >= FRAME_PLANS:
+                        cps.pop(next(iter(cps)))
+                    cp = cps[key] = CompiledPass(self, nets_in, seeds, fn=self._later_nets)
+                else:
+                    cps[key] = cps.pop(key)                   # most recently used last
+                out = {k: v.clone() for k, v in cp._issue(nets_in, seeds).items()}     # the plan's buffers belong to its next replay
+            else:
+                out = self._later_nets(nets_in, seeds)
             out["icn_u8"] = pu.lab2bgr(out["icn_u8"])
             out["geom"] = geom
         return out
@@ -856,7 +883,7 @@ class VehiclePipeline:
         state = first["state"]
         yield first if len(first) > 1 else None
         for sc in later_scenes:
-            yield self.run_later_frame(sc, state)
+            yield self.run_later_frame(sc, state, replay=replay)
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
                  check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:

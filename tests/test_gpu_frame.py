@@ -473,6 +473,15 @@ def test_run_later_frame_matches_the_oracle():
     again = pipe.run_later_frame(later, f0r["state"])
     for k in ("icn_u8", "vunet_u8", "frame_icn", "frame_vunet"):
         assert torch.equal(again[k], got[k]), k
+    # the later frame's two networks as ONE recorded-plan replay (round 4): recorded on the first call, replayed on the second -
+    # the eager frame's bits both times, and the replayed buffers do not alias the results handed out
+    rep1 = pipe.run_later_frame(later, f0["state"], replay=True)
+    rep2 = pipe.run_later_frame(later, f0["state"], replay=True)
+    for k in ("icn_u8", "vunet_u8", "frame_icn", "frame_vunet", "geom"):
+        assert torch.equal(rep1[k], got[k]) and torch.equal(rep2[k], got[k]), k
+    assert rep1["vunet_u8"].data_ptr() != rep2["vunet_u8"].data_ptr()
+    clip = list(pipe.run_clip_frames(first, [later, later], replay=True))
+    assert len(clip) == 3 and torch.equal(clip[2]["frame_vunet"], got["frame_vunet"]) and torch.equal(clip[0]["kp_idx"], f0["kp_idx"])
     with pytest.raises(ValueError):
         pipe.run_later_frame(synth_frame(1, (360, 640), DEV, seed=43), f0["state"])
 
