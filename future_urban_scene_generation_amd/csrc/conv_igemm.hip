@@ -4,6 +4,7 @@
 #include <mutex>
 #include "conv_kernel_tapunit.h"
 #include "conv_kernel_small.h"
+#include "conv_kernel_tapunit_f32.h"
 
 namespace fusg {
 
@@ -496,6 +497,45 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
         if (e != hipSuccess) { set_error("conv2d pointwise launch: %s", hipGetErrorString(e)); return FUSG_ERR_LAUNCH; }
         note_conv_kernel(FUSG_CONV_POINTWISE);
         return FUSG_OK;
+    }
+    // few-channel k x k layers (the 7x7 stems) in exact fp32 (round 4): conv_kernel_tapunit_f32.h
+    if (d->wfrag_order == 2 && d->precision == FUSG_PREC_F32 && d->wfrag_f32 != nullptr && (((uintptr_t)d->wfrag_f32) & 15) == 0 &&
+        getenv("FUSG_NO_F32_HALO") == nullptr) {
+        const int nunits = d->kh * d->kw * (d->c0k / 4);
+        const bool ok = nphase == 1 && d->upsample == 0 && d->ksplit <= 1 && !has1 && d->c0k >= 4 && d->c0k <= 24 && d->c0k % 4 == 0 &&
+                        d->kh >= 1 && d->kw >= 1 && d->dil == 1 && d->qh % 8 == 0 && d->qw % 16 == 0 && nunits <= 320 &&
+                        d->k_pad >= d->kh * d->kw * d->c0k && (d->q_oy | d->q_ox) == 0 && !d->tile_list && !env_switches().no_halo;
+        if (ok) {
+            TapUnitF h;
+            memset(&h, 0, sizeof(h));
+            h.c = k;
+            h.stride = d->stride; h.pad_h = d->pad_h; h.pad_w = d->pad_w;
+            h.HH = 7 * d->stride + d->kh; h.HW = 15 * d->stride + d->kw;
+            h.CP = d->c0k; h.PP = d->c0k;
+            h.RP = h.HW * h.PP;
+            h.nunits = nunits;
+            h.wfrag = (const float*)d->wfrag_f32;
+            h.nt32 = d->cout_pad / 32;
+            const int upp = d->c0k / 4;
+            for (int j = 0; j < nunits; ++j) {
+                const int tap = j / upp, u = j - tap * upp, ky = tap / d->kw, kx = tap - ky * d->kw;
+                h.uoff[j] = ky * h.RP + kx * h.PP + u * 4;
+            }
+            int bn = d->cout_pad % 128 == 0 ? 128 : (d->cout_pad % 64 == 0 ? 64 : 32);
+            if (const int v = env_switches().halo_bn; (v == 32 || v == 64 || v == 128) && d->cout_pad % v == 0) bn = v;
+            h.tiles_x = d->qw / 16; h.tiles_per_img = (d->qh / 8) * h.tiles_x;
+            h.c.MT = (int)x0.n * h.tiles_per_img; h.c.NT = d->cout_pad / bn;
+            h.c.ksplit = 1; h.c.wscale = nullptr; h.c.status = nullptr;
+            if ((size_t)h.HH * h.RP * sizeof(float) <= 80 * 1024 && h.HH * h.HW * (h.CP / 4) <= 256 * 8) {
+                dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
+                e = bn == 128 ? launch_tapunit_f32_128(h, hgrid, s, pk) : bn == 64 ? launch_tapunit_f32_64(h, hgrid, s, pk)
+                                                                                   : launch_tapunit_f32_32(h, hgrid, s, pk);
+                if (e != hipSuccess) { set_error("conv2d fp32 tap-unit launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
+                note_conv_kernel(FUSG_CONV_TAPUNIT_F32);
+                prof_end(0, s);
+                return FUSG_OK;
+            }
+        }
     }
     // few-channel k x k layers (the 7x7 stems): tap-unit kernel (conv_kernel_tapunit.h)
     if (d->wfrag_order == 2) {

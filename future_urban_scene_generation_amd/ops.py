@@ -470,7 +470,7 @@ def conv(plan: ConvPlan, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, *,
             d.wfrag_order = dev["wfrag_order"]
             if prec_name == "bf16" and dev.get("wfrag_bf16") is not None:
                 d.wfrag_bf16 = dev["wfrag_bf16"].data_ptr()
-            if prec_name == "f32" and dev["wfrag_order"] in (0, 1) and not _env_set("FUSG_NO_F32_HALO"):
+            if prec_name == "f32" and dev["wfrag_order"] in (0, 1, 2) and not _env_set("FUSG_NO_F32_HALO"):
                 ff = plan.frag_f32_dev()                  # exact-fp32 halo kernel (built on first use)
                 if ff is not None:
                     d.wfrag_f32 = ff.data_ptr()

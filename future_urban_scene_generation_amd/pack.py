@@ -76,7 +76,12 @@ class ConvPlan:
         """fusg_conv_desc.wfrag_f32 (exact-fp32 halo kernel), built and uploaded on first use: only `precision="f32"` passes
         and the range guard's fallback need it.  None when the layer cannot use the halo kernel."""
         if "wfrag_f32" not in self.dev:
-            ff = frag_f32(self.wpack, self) if (self.nphase == 1 and self.dev.get("wfrag") is not None and self.dev["wfrag_order"] in (0, 1)) else None
+            ff = None
+            if self.nphase == 1 and self.dev.get("wfrag") is not None:
+                if self.dev["wfrag_order"] in (0, 1):
+                    ff = frag_f32(self.wpack, self)
+                elif self.dev["wfrag_order"] == 2:
+                    ff = frag_tapunit_f32(self.wpack, self)                 # few-channel stems: units of 4 channels
             if ff is not None and self.s2d_ok():
                 ff = ff[s2d_tap_order(self.kh)].contiguous()
             self.dev["wfrag_f32"] = None if ff is None else ff.to(self.dev["wpack"].device).contiguous()
@@ -207,6 +212,20 @@ def frag_tapunit(wsplit: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:
     wk = wk.view(2, nt32, 32, nsteps, 2, 8)                     # hl, nt, r, step, h, j
     wk = wk.permute(3, 1, 0, 4, 2, 5)                           # step, nt, hl, h, r, j
     return wk.reshape(nsteps, nt32, 2, 64, 8).contiguous()
+
+
+def frag_tapunit_f32(wpack: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:
+    """fp32 weights of a few-channel layer for the exact-fp32 tap-unit kernel (csrc/conv_kernel_tapunit_f32.h): K walked in units of
+    4 channels of one tap -> [unit][cout_pad/32][64 lanes][2] with lane = g * 32 + column holding w[column][4 unit + g] and
+    w[column][4 unit + 2 + g]: what lane half g feeds the unit's two v_mfma_f32_32x32x2_f32."""
+    w = wpack[0]                                                # [cout_pad, k_pad], K order (tap, channel) with c0k per tap
+    taps, c = plan.kh * plan.kw, plan.c0k
+    assert c % 4 == 0
+    nunits = taps * c // 4
+    nt32 = plan.cout_pad // 32
+    wk = w[:, :nunits * 4].reshape(nt32, 32, nunits, 2, 2)      # nt, col, unit, e, g
+    wk = wk.permute(2, 0, 4, 1, 3)                              # unit, nt, g, col, e
+    return wk.reshape(nunits, nt32, 64, 2).contiguous()
 
 
 def _entry(dy: int, dx: int, coff: int, src: int, invalid: bool = False):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 112
+#define FUSG_VERSION 113
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -200,7 +200,9 @@ typedef struct fusg_conv_desc {
      * [tap][chunk32][cout_pad/32][16-column half][h][64 lanes][4 floats] with lane = g * 16 + column holding
      * w[column][32 chunk + 16 h + 4 g + e], e = 0..3, same tap order as `wfrag` (pack.py: frag_f32).  Given (with the
      * filter geometry above), a qualifying FUSG_PREC_F32 launch runs on the halo kernel in exact fp32 instead of the
-     * generic gather; NULL keeps the generic gather. */
+     * generic gather; NULL keeps the generic gather.
+     * With wfrag_order 2 (few-channel stems) it holds the tap-unit form instead: [unit of 4 channels][cout_pad/32][64 lanes][2]
+     * floats, lane = g * 32 + column holding w[column][4 unit + g], w[column][4 unit + 2 + g] (pack.py: frag_tapunit_f32). */
     const void*    wfrag_f32;
     /* Optional, split-K launches: `splitk_counters_len` device int32 words that are ZERO when the launch starts (the
      * launch leaves them zero).  Given, the workgroup that finishes a tile's last K-slice sums the slices (in slice
@@ -474,7 +476,8 @@ enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 
        FUSG_CONV_TAPUNIT = 4, FUSG_CONV_HALO_BF16 = 5, FUSG_CONV_BNECK = 6 /* fusg_hg_bottleneck */,
        FUSG_CONV_POINTWISE = 7 /* 1x1 from <= 8 channels: streaming fp32 FMA kernel, no matrix cores */,
        FUSG_CONV_SMALL = 8 /* small output images (<= 64 pixels): latency-built split-fp16 kernel (csrc/conv_kernel_small.h) */,
-       FUSG_CONV_HALO_F32 = 9 /* halo kernel in exact fp32 (v_mfma_f32_16x16x4_f32, fusg_conv_desc.wfrag_f32) */ };
+       FUSG_CONV_HALO_F32 = 9 /* halo kernel in exact fp32 (v_mfma_f32_16x16x4_f32, fusg_conv_desc.wfrag_f32) */,
+       FUSG_CONV_TAPUNIT_F32 = 10 /* few-channel stems in exact fp32 (csrc/conv_kernel_tapunit_f32.h; wfrag_order 2 + wfrag_f32) */ };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their

@@ -223,8 +223,17 @@ def test_conv_tapunit_stems(cin, cout, k, stride, pad, pm, H, W, precision):
         return F.conv2d(xin, w, b, stride=stride)
 
     got = ops.conv(plan, xd, ksplit=1)
-    assert ops.last_conv_kernel() == (4 if precision == "f16x3" else 0)
+    assert ops.last_conv_kernel() == (4 if precision == "f16x3" else 10)          # (f32: the exact-fp32 tap-unit kernel, round 4)
     _close(got, ref_of(x))
+    if precision == "f32":                                                         # ... against the generic fp32 gather it replaces
+        import os
+        os.environ["FUSG_NO_F32_HALO"] = "1"
+        try:
+            old = ops.conv(plan, xd, ksplit=1)
+            assert ops.last_conv_kernel() == 0
+        finally:
+            del os.environ["FUSG_NO_F32_HALO"]
+        _close(got, old.cpu(), rtol=1e-5, atol=2e-6 * float(old.abs().max()))
     _close(ops.conv(plan, xd, ksplit=1, pre_op=L.PRE_ELU), ref_of(F.elu(x)))
     sc, sh = torch.rand(2, plan.c0k, generator=torch.Generator().manual_seed(4)) + 0.5, _rand(2, plan.c0k, seed=5) * 0.2
     xa = torch.relu(x * sc[:, :cin, None, None] + sh[:, :cin, None, None])

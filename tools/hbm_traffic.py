@@ -21,9 +21,10 @@ import os
 import sys
 
 
-CONV_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "conv_splitk_reduce", "hg_bneck")     # every dispatch a fusg_conv2d call makes
+CONV_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "conv_splitk_reduce", "hg_bneck", "conv_small", "conv_pointwise")     # every dispatch a fusg_conv2d call makes
 # one fusg_conv2d call = one launch, except split-K launches, which add their reduce dispatch: calls = main dispatches
-MAIN_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "hg_bneck")
+# (round 4: + the small-image kernel and the streaming pointwise kernel, which the round-3 list missed)
+MAIN_KERNELS = ("conv_igemm", "conv_halo", "conv_tapunit", "hg_bneck", "conv_small", "conv_pointwise")
 
 
 def load(d, counter):
