@@ -365,7 +365,7 @@ def warp_planes_batch(src_planes: torch.Tensor, jobs_per_vehicle) -> torch.Tenso
             Hs.append(H12)
     if Hs:                                                        # every job reads its plane and writes its slot in place
         flat = flat.contiguous()
-        minv = np.stack([np.linalg.inv(np.asarray(h, dtype=np.float64)) for h in Hs]).reshape(len(Hs), 9)
+        minv = np.linalg.inv(np.asarray(Hs, dtype=np.float64).reshape(len(Hs), 3, 3)).reshape(len(Hs), 9)   # LAPACK getrf/getri per matrix, as one call
         minv_d = ops.h2d(minv, flat.device)
         index = ops.h2d(np.stack([src_idx, dst_idx], 1).astype(np.int32), flat.device)
         with torch.cuda.device(flat.device):
