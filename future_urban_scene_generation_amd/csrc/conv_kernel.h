@@ -178,9 +178,10 @@ __device__ __forceinline__ void res_prefetch(const ConvK& p, int lane, int ncol_
         }
 }
 
-template <int TM, int TN, int PITCH = TN * 32, typename PixFn, typename StatFn>
+template <int TM, int TN, typename PixFn, typename StatFn>
 __device__ __forceinline__ void epilogue_rows(const ConvK& p, float* wlds, int lane, int ncol_base, PixFn pix, StatFn stat_base,
                                               const ResRegs<TM, TN>& rr, bool use_rr) {
+    constexpr int PITCH = TN * 32;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -262,70 +263,20 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& p, float* wlds, const 
     epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base, none, false);
 }
 
-// the same for accumulators of 16 x 16 MFMA tiles computed TRANSPOSED (weights as the A operand, pixels as B - the halo
-// kernel, round 4): acc[patch row of 16 pixels][group of 16 columns], C/D map: pixel = lane & 15, columns 4 (lane >> 4) .. +3.
-// A lane's four values are consecutive columns of one pixel: one 16-byte LDS store each, into rows of TN * 32 + 4 floats (the
-// 16-byte lane stride of a plain TN * 32 pitch would put the 8 lanes of a ds_write_b128 service group on one bank group).
-template <int TN> constexpr int epi_pitch_t() { return TN * 32 + 4; }
+// the same for accumulators of v_mfma_f32_16x16x32_f16 tiles: acc[row group of 16][column group of 16], C/D map
+// col = lane & 15, row = (lane >> 4) * 4 + reg
 template <int TM, int TN, typename PixFn, typename StatFn>
-__device__ __forceinline__ void epilogue_vec16t(const ConvK& p, float* wlds, const f32x4 (&acc)[2 * TM][2 * TN], int lane,
-                                                int ncol_base, PixFn pix, StatFn stat_base, const ResRegs<TM, TN>& rr, bool use_rr) {
-    constexpr int PITCH = epi_pitch_t<TN>();
+__device__ __forceinline__ void epilogue_vec16(const ConvK& p, float* wlds, const f32x4 (&acc)[2 * TM][2 * TN], int lane,
+                                               int ncol_base, PixFn pix, StatFn stat_base, const ResRegs<TM, TN>& rr, bool use_rr) {
+    constexpr int PITCH = TN * 32;
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2 * TN; ++j)
-            *(f32x4*)(wlds + (i * 16 + (lane & 15)) * PITCH + j * 16 + (lane >> 4) * 4) = acc[i][j];
-    epilogue_rows<TM, TN, PITCH>(p, wlds, lane, ncol_base, pix, stat_base, rr, use_rr);
-}
-
-// ... and without the detour through LDS (launches without fused statistics): bias / activation / residuals / 16-byte store
-// straight from the accumulator registers - a wave instruction writes 64 contiguous bytes of 16 pixels.  What the detour
-// cost on the 128-pixel x 32-column wave tile: 64 ds_write_b32 + 16 ds_read_b128 per lane, a workgroup barrier and 64 KiB of
-// LDS per workgroup, per launch - a fixed ~2000 cycles per wave next to 768 per (chunk, tap) step.
-template <int NM, int NN> struct ResRegsT { f32x4 v[NM][NN]; };
-template <int NM, int NN, typename PixFn>
-__device__ __forceinline__ void res_prefetch_t(const ConvK& p, int lane, int ncol_base, PixFn pix, ResRegsT<NM, NN>& rr) {
 #pragma unroll
-    for (int j = 0; j < NN; ++j) {
-        const int n = ncol_base + j * 16 + (lane >> 4) * 4;
-        const bool nvalid = n < p.Cout;
-        PixOff co;
-        co.d = co.r0 = co.r1 = 0;
-        if (nvalid) chan_offsets(p, n, co);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            PixOff po;
-            const bool ok = pix(i * 16 + (lane & 15), po);
-            rr.v[i][j] = *(const f32x4*)((nvalid && ok) ? p.res0 + po.r0 + co.r0 : p.zeros);
-        }
-    }
-}
-template <int NM, int NN, typename PixFn>
-__device__ __forceinline__ void epilogue_direct_t(const ConvK& p, const f32x4 (&acc)[NM][NN], int lane, int ncol_base, PixFn pix,
-                                                  const ResRegsT<NM, NN>& rr, bool use_rr) {
-#pragma unroll
-    for (int j = 0; j < NN; ++j) {
-        const int n = ncol_base + j * 16 + (lane >> 4) * 4;
-        if (n >= p.Cout) continue;                                      // (cout % 4 == 0 under vec_epi: all four columns or none)
-        const f32x4 bs = *(const f32x4*)(p.bias + n);
-        f32x4 wsc = {1.f, 1.f, 1.f, 1.f};
-        if (p.wscale) wsc = *(const f32x4*)(p.wscale + n);
-        PixOff co;
-        chan_offsets(p, n, co);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-            PixOff po;
-            if (!pix(i * 16 + (lane & 15), po)) continue;
-            f32x4 v = acc[i][j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = act_apply(fmaf(v[c], wsc[c], bs[c]), p.act);
-            if (use_rr) v += rr.v[i][j];
-            else if (p.res0) v += *(const f32x4*)(p.res0 + po.r0 + co.r0);
-            if (p.res1) v += *(const f32x4*)(p.res1 + po.r1 + co.r1);
-            *(f32x4*)(p.dst + po.d + co.d) = v;
-        }
-    }
+            for (int r = 0; r < 4; ++r)
+                wlds[(i * 16 + (lane >> 4) * 4 + r) * PITCH + j * 16 + (lane & 15)] = acc[i][j][r];
+    epilogue_rows<TM, TN>(p, wlds, lane, ncol_base, pix, stat_base, rr, use_rr);
 }
 
 // ---- in-launch split-K combine ---------------------------------------------------------------------------------

@@ -300,11 +300,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                     F.f[j][ct][hl] = *(const h8*)(base + ((j * 2 + ct) * (BF ? 1 : 2) + hl) * 512);
     };
 
-    // [patch row of the wave][16-column group].  The products run TRANSPOSED (round 4): the weight fragment is the A operand, the
-    // pixel fragment B (both have the same register layout), so a lane ends up with 4 consecutive output columns of ONE pixel
-    // (C/D map: pixel = lane & 15, columns 4 (lane >> 4) + reg) and the epilogue stores 16 bytes per lane straight from the
-    // accumulators (conv_kernel.h, epilogue_direct_t).  The same dot products in the same k order: bit-identical values.
-    f32x4 acc[2 * TM][2 * TN];
+    f32x4 acc[2 * TM][2 * TN];                        // [patch row of the wave][16-column group]
 #pragma unroll
     for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
@@ -338,7 +334,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
 #pragma unroll
                             for (int ct = 0; ct < 2; ++ct) {
                                 const f32x4 bv = __builtin_bit_cast(f32x4, F.f[j][ct][h]);
-                                acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], h ? a1[i][e] : a0[i][e], acc[i][2 * j + ct], 0, 0, 0);
+                                acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(h ? a1[i][e] : a0[i][e], bv[e], acc[i][2 * j + ct], 0, 0, 0);
                             }
         } else if constexpr (BF) {
             bf8 ab[2 * TM];
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, F.f[j][ct][0]), ab[i],
+                        acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[i], __builtin_bit_cast(bf8, F.f[j][ct][0]),
                                                                                        acc[i][2 * j + ct], 0, 0, 0);
         } else {
             h8 ah[2 * TM], al[2 * TM], bs[TN][2];
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct)
                             acc[i][2 * j + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                term == 0 ? F.f[j][ct][0] : term == 1 ? F.f[j][ct][1] : bs[j][ct], term == 2 ? al[i] : ah[i],
+                                term == 2 ? al[i] : ah[i], term == 0 ? F.f[j][ct][0] : term == 1 ? F.f[j][ct][1] : bs[j][ct],
                                 acc[i][2 * j + ct], 0, 0, 0);
         }
     };
@@ -505,23 +501,23 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
         // ---- K split: partial tiles -> LDS ([wave][128 rows][32 columns] fp32, over the halo images), summed in wave order by
         // the wave that finishes those rows: wave (wk, wn) takes rows 128 / KS * wk ... of column tile wn
         constexpr int RW = 128 / KS, TME = RW / 32;
-        constexpr int SP = epi_pitch_t<1>();                           // slab row pitch in floats (36: conflict-free 16-byte lane stores)
         __syncthreads();                                               // every wave is done with the halo images
         float* slabs = (float*)smem_h;
-        float* mine = slabs + wave * (128 * SP);
+        float* mine = slabs + wave * (128 * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) *(f32x4*)(mine + (i * 16 + (lane & 15)) * SP + j * 16 + (lane >> 4) * 4) = acc[i][j];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(i * 16 + (lane >> 4) * 4 + r) * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
         __syncthreads();
         const int rows0 = RW * wk;
-        float* dstw = slabs + wn * (128 * SP) + rows0 * SP;           // column wn's slab of K-split 0: the sum lands here
+        float* dstw = slabs + wn * (128 * 32) + rows0 * 32;           // column wn's slab of K-split 0: the sum lands here
         for (int e = lane; e < RW * 8; e += 64) {                      // RW rows x 8 float4
-            const int eo = (e >> 3) * SP + (e & 7) * 4;
-            f32x4 sum = *(const f32x4*)(dstw + eo);
+            f32x4 sum = *(const f32x4*)(dstw + e * 4);
 #pragma unroll
-            for (int k2 = 1; k2 < KS; ++k2) sum += *(const f32x4*)(slabs + (k2 * WN + wn) * (128 * SP) + rows0 * SP + eo);
-            *(f32x4*)(dstw + eo) = sum;
+            for (int k2 = 1; k2 < KS; ++k2) sum += *(const f32x4*)(slabs + (k2 * WN + wn) * (128 * 32) + rows0 * 32 + e * 4);
+            *(f32x4*)(dstw + e * 4) = sum;
         }
         auto pixk = [&](int row, PixOff& po) {
             const int rr = rows0 + row;
@@ -533,7 +529,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
         };
         if (p.vec_epi) {
             ResRegs<TME, 1> none;
-            epilogue_rows<TME, 1, SP>(p, dstw, lane, nt * BN + wn * 32, pixk, statk, none, false);
+            epilogue_rows<TME, 1>(p, dstw, lane, nt * BN + wn * 32, pixk, statk, none, false);
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -544,7 +540,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                 PixOff po, co;
                 pixk(row, po);
                 chan_offsets(p, n, co);
-                epi_store(p, po, co, p.bias[n], p.wscale ? p.wscale[n] : 1.f, dstw[row * SP + (e & 31)]);
+                epi_store(p, po, co, p.bias[n], p.wscale ? p.wscale[n] : 1.f, dstw[e]);
             }
         }
         return;
@@ -565,7 +561,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
             // (the prefetch set would be 128 more registers)
             constexpr int TH = TM / 2;
             __syncthreads();
-            float* wlds = (float*)smem_h + wave * (TH * 32 * epi_pitch_t<TN>());
+            float* wlds = (float*)smem_h + wave * (TH * 32 * TN * 32);
             ResRegs<TH, TN> none;
             auto do_half = [&](auto halfc) __attribute__((always_inline)) {
                 constexpr int half = decltype(halfc)::value;           // compile-time: the accumulators stay in registers
@@ -576,49 +572,38 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                     for (int j = 0; j < 2 * TN; ++j) sub[i][j] = acc[half * 2 * TH + i][j];
                 auto pixh = [&](int row, PixOff& po) { return pixfn(half * TH * 32 + row, po); };
                 auto stath = [&](int i) -> float* { return statfn(half * TH + i); };
-                epilogue_vec16t<TH, TN>(p, wlds, sub, lane, nt * BN + wn * TN * 32, pixh, stath, none, false);
+                epilogue_vec16<TH, TN>(p, wlds, sub, lane, nt * BN + wn * TN * 32, pixh, stath, none, false);
             };
             do_half(std::integral_constant<int, 0>{});
             do_half(std::integral_constant<int, 1>{});
             return;
         } else {
-#ifndef FUSG_EPI_LDS
-        if (p.stats == nullptr) {
-            // straight from the accumulators: no barrier, no LDS (the residual tile is fetched first and lands while bias / activation run)
-            ResRegsT<2 * TM, 2 * TN> rt;
-            const bool pre = p.res0 != nullptr;
-            if (pre) res_prefetch_t<2 * TM, 2 * TN>(p, lane, nt * BN + wn * TN * 32, pixfn, rt);
-            epilogue_direct_t<2 * TM, 2 * TN>(p, acc, lane, nt * BN + wn * TN * 32, pixfn, rt, pre);
-            return;
-        }
-#endif
-        // fused statistics (per-column sums over 32 pixels): the tile goes through LDS, rows come back as 16-byte items
         ResRegs<TM, TN> rr;
         const bool pre = p.res0 != nullptr;
         if (pre) res_prefetch<TM, TN>(p, lane, nt * BN + wn * TN * 32, pixfn, rr);     // in flight across the barrier and the LDS detour
         __syncthreads();
-        float* wlds = (float*)smem_h + wave * (TM * 32 * epi_pitch_t<TN>());
-        epilogue_vec16t<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn, rr, pre);
+        float* wlds = (float*)smem_h + wave * (TM * 32 * TN * 32);
+        epilogue_vec16<TM, TN>(p, wlds, acc, lane, nt * BN + wn * TN * 32, pixfn, statfn, rr, pre);
         return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j)                       // C/D map of the transposed 16x16 tile: pixel = lane & 15, column = 4 (lane >> 4) + reg
+    for (int j = 0; j < 2 * TN; ++j) {                     // C/D map of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + reg
+        const int n = nt * BN + wn * TN * 32 + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        PixOff co;
+        chan_offsets(p, n, co);
+        const float bias = p.bias[n], wsc = p.wscale ? p.wscale[n] : 1.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = nt * BN + wn * TN * 32 + j * 16 + (lane >> 4) * 4 + r;
-            if (n >= p.Cout) continue;
-            PixOff co;
-            chan_offsets(p, n, co);
-            const float bias = p.bias[n], wsc = p.wscale ? p.wscale[n] : 1.f;
+        for (int i = 0; i < 2 * TM; ++i)
 #pragma unroll
-            for (int i = 0; i < 2 * TM; ++i) {
-                const int row = wm * TM * 32 + i * 16 + (lane & 15);
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * TM * 32 + i * 16 + (lane >> 4) * 4 + r;
                 PixOff po;
                 pix_offsets_yx(p, b, oy0 + (row >> 4), ox0 + (row & 15), po);
-                epi_store(p, po, co, bias, wsc, acc[i][j][r]);       // (an NCHW destination: 16 consecutive pixels per 16 lanes)
+                epi_store(p, po, co, bias, wsc, acc[i][j][r]);
             }
-        }
+    }
 }
 
 // LDS pitch of one halo row in halves (rows need no padding: one ds_read_b128 instruction reads one patch row)
@@ -631,11 +616,7 @@ template <int TM, int TN, int WM, int WN, int KS = 1>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, int mode) {      // mode: 0 split-fp16, 1 bf16, 2 exact fp32
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
-    constexpr size_t EPI = (size_t)4 * TM * 32 * epi_pitch_t<TN>() * sizeof(float);   // epilogue detour of the statistics launches (K split: the four partial tiles)
-    if ((k.c.stats != nullptr || KS > 1) && lds < EPI) lds = EPI;      // (the other launches store straight from the accumulators)
-#ifdef FUSG_EPI_LDS
-    if (lds < EPI) lds = EPI;
-#endif
+    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour (K split: the four partial tiles)
     const int touch_off = (int)lds;
     lds += TOUCH_LDS_BYTES;
     const int ni = (HP * 8 + 255) / 256;
@@ -678,7 +659,7 @@ hipError_t launch_halo_big(const HaloK& k, dim3 grid, hipStream_t s, int pk) {
     static_assert(32 * TM * WM == 256, "16 x 16 pixel patch");
     const int HP = k.HH * k.HW;
     size_t lds = (size_t)k.HH * halo_row_pitch(k.HW) * sizeof(_Float16);                        // ONE (bf16) halo image
-    constexpr size_t EPI = (size_t)4 * (TM / 2) * 32 * epi_pitch_t<TN>() * sizeof(float);
+    constexpr size_t EPI = (size_t)4 * (TM / 2) * 32 * TN * 32 * sizeof(float);
     if (lds < EPI) lds = EPI;
     const int touch_off = (int)lds;
     lds += TOUCH_LDS_BYTES;
