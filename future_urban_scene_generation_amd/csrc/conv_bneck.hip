@@ -44,6 +44,17 @@ constexpr size_t bneck_lds(int planes) { return (size_t)(2 * BN_SROWS * 32 + 2 *
 
 template <int CT> struct WFrag { h8 f[CT][2]; };      // [16-column tile][hi | lo]
 
+// Diagnostic build only (-DFUSG_BNECK_STAMPS, tools/bneck_stamps.py): s_memtime at the phase boundaries of the first 64 workgroups, into
+// a buffer nothing else reads.  The product build executes no stamp.
+#ifdef FUSG_BNECK_STAMPS
+__device__ unsigned long long g_bneck_stamps[64 * 12];
+#define FUSG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_bneck_stamps[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FUSG_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_bneck_stamps[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FUSG_STAMP(i) do {} while (0)
+#define FUSG_STAMP_RT(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(const h8 a, const h8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -64,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lp = lane & 15, lg = lane >> 4;           // pixel of the fragment, 8-k slot
+    FUSG_STAMP_RT(8);
+    FUSG_STAMP(0);
     int tile;
     {
         const int nb = gridDim.x, bid = blockIdx.x;
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
 
     const int nch1 = k.Cin >> 5;
     WFrag<CT1> wA, wB;
+    FUSG_STAMP(1);
     issue(0);
     load_w(wA, k.w1, 0, NCH, wave * CT1);
     for (int c = 0; c < nch1; c += 2) {
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
     }
 
     // first weights of conv2 on their way while conv1's result is written to T
+    FUSG_STAMP(2);
     WFrag<CT1> w0, w1, w2;
     load_w(w0, k.w2, 0, NCH, wave * CT1);                       // step 0 = (chunk 0, tap 0)
     load_w(w1, k.w2, NCH, NCH, wave * CT1);                     // step 1 = (chunk 0, tap 1): slab tap * NCH + chunk
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
         }
     }
     __syncthreads();
+    FUSG_STAMP(3);
 
     // ------------------------------------------------------------------ conv2: 3x3 over T
     f32x4 acc2[4][CT1];
@@ -264,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
             compute2(w2, c, tap + 2);
         }
     }
+    FUSG_STAMP(4);
     __syncthreads();                                            // T is dead: U may overwrite it
 
     // conv3's first weights, then conv2's result into U
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
         }
     }
     __syncthreads();
+    FUSG_STAMP(5);
 
     // ------------------------------------------------------------------ conv3: 1x1 P -> 2 P, this wave's P / 2 channels
     f32x4 acc3[4][CT3];
@@ -320,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
         compute3(v1, c + 1);
     }
 
+    FUSG_STAMP(6);
     if (amax >= F16X3_LIMIT && k.status) *k.status = 1;
 
     // ------------------------------------------------------------------ + bias, + residual, store
@@ -340,6 +359,8 @@ __global__ __launch_bounds__(256, 2) void hg_bneck_h3(const BneckK k) {
             *(f32x4*)(dp + n0) = v;
         }
     }
+    FUSG_STAMP(7);
+    FUSG_STAMP_RT(9);
 }
 
 
@@ -641,3 +662,8 @@ static int bneck_impl(const fusg_bneck_desc* d, void* stream) {
     return FUSG_OK;
 }
 extern "C" int fusg_hg_bottleneck(const fusg_bneck_desc* d, void* stream) { return fusg::plan_dispatch(bneck_impl, stream, d); }
+#ifdef FUSG_BNECK_STAMPS
+extern "C" int fusg_debug_bneck_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fusg::g_bneck_stamps), sizeof(unsigned long long) * 64 * 12) == hipSuccess ? 0 : 1;
+}
+#endif
