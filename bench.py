@@ -356,8 +356,13 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    # FUSG_DIST_FORCE=1 (test hook, tests/test_bench_gpu.py): treat ONE rank as a multi-rank job - the process group is initialised and every
+    # collective of the multi-rank path (weight broadcast, crop gather, barrier, all-reduce of the timings) goes through RCCL with a
+    # communicator of one rank: what a box with a single card can execute of the RCCL path
+    multi = world > 1 or os.environ.get("FUSG_DIST_FORCE") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -368,7 +373,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         # RCCL ("nccl" on ROCm).  FUSG_DIST_BACKEND=gloo rehearses the multi-rank code path where the ranks have
         # to share one card (development boxes): the gathers are then staged through host memory.
         if backend == "nccl":
@@ -381,7 +386,7 @@ def main():
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, gather_in_order, shard_range, synth_batch
 
     torch.set_grad_enabled(False)
-    if world > 1:
+    if world > 1:                                       # (not `multi`: one rank keeps the whole host)
         # N ranks share one host: each draws its VUnet noise with torch.randn on the CPU and issues ~370 launches
         # per pass - without a cap every rank starts a thread pool as wide as the machine
         try:
@@ -390,7 +395,7 @@ def main():
             ncpu = os.cpu_count() or 1
         torch.set_num_threads(max(1, min(16, ncpu // world)))
     sds, bcast_ms = None, None
-    if args.broadcast_weights and world > 1:
+    if args.broadcast_weights and multi:
         from future_urban_scene_generation_amd.pipeline import broadcast_state_dicts, load_schema
         from future_urban_scene_generation_amd.synth import synth_state_dict
         nets = ("hg", "icn", "vunet") + (("edge", "inpaint") if args.inpaint else ())
@@ -428,7 +433,7 @@ def main():
             out = cp.run(batch, vehicle_seeds=seeds, check="async")
         else:
             out = pipe.run(batch, vehicle_seeds=seeds, check="async")
-        if world > 1:                                   # the path's only exchange: crops -> rank 0
+        if multi:                                       # the path's only exchange: crops -> rank 0
             t_g = time.perf_counter()
             crops = torch.cat([out["icn_u8"], out["vunet_u8"]], dim=-1)
             gather_in_order(crops, n_total)
@@ -437,7 +442,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -448,7 +453,7 @@ def main():
     def keep_settling(t_s):
         # every rank must run the same number of steps (a step contains collectives): rank 0's clock decides
         go = torch.tensor([1 if time.perf_counter() - t_s < args.settle_s else 0], dtype=torch.int32, device=coll_dev)
-        if world > 1:
+        if multi:
             dist.broadcast(go, src=0)
         return bool(go.item())
 
@@ -550,13 +555,13 @@ def main():
             roofline.update(hbm_extra)
         power = sampler.stop() if sampler else None
         tstat = torch.tensor([dt, -dt, 1.0 if out_of_range else 0.0], dtype=torch.float64, device=coll_dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(tstat, op=dist.ReduceOp.MAX)
         dt_max, dt_min, bad = float(tstat[0]), -float(tstat[1]), bool(tstat[2] > 0)
         leg = {"value": round(n_total * args.steps / dt_max, 3), "unit": "crops/s",
                "ms_per_step": round(dt_max / args.steps * 1e3, 3), "dtype": DTYPE[prec], "roofline": roofline,
                "settle_steps": settle, "range_status_raised": bad}
-        if world > 1:
+        if multi:
             leg["per_rank_crops_per_s"] = {"min": round(args.batch * args.steps / dt_max, 2),
                                            "max": round(args.batch * args.steps / dt_min, 2)}
             leg["gather_enqueue_ms_per_step"] = round(sum(gather_ms) / max(1, len(gather_ms)), 3)
@@ -685,7 +690,7 @@ def main():
                                      "kernels write; a caller with standard NCHW tensors pays four conversion launches per pass)"},
                 "roofline": h["roofline"], "cpu_baseline": cpu_baseline,
                 "precision_legs": {k: {kk: vv for kk, vv in v.items() if kk != "power"} for k, v in legs.items()}}
-        if world > 1:
+        if multi:
             # "rccl_ranks" only when RCCL ("nccl" on ROCm) really carried the collectives; a gloo rehearsal says "dist_ranks"
             line["rccl_ranks" if dist.get_backend() == "nccl" else "dist_ranks"] = dist.get_world_size()
             line["dist_backend"] = dist.get_backend()
@@ -701,7 +706,7 @@ def main():
         line["streams"] = "serial" if os.environ.get("FUSG_STREAMS", "1") == "0" else "one HIP stream per network branch (+ one for the VUnet's shape encoder)"
         line["issue"] = "recorded plan replay (fusg_plan_run)" if args.replay else "eager (one ctypes call per launch)"
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -32,6 +32,16 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 _GATHER_BUFS = {}
 
 
+def _one_rank(group=None) -> bool:
+    """No process group, or a group of one rank: the multi-rank code paths are skipped.  FUSG_DIST_FORCE=1 (test hook) keeps them for
+    a group of ONE rank, so that a box with a single card executes the RCCL collectives of every sharded path (broadcast of the
+    weights, gather of the crops / states, the comm-stream pipelining) with a one-rank communicator."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("FUSG_DIST_FORCE") != "1"
+
+
 def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0) -> Optional[torch.Tensor]:
     """Gather per-rank shards ([n_local, ...], same trailing shape) to `dst` in vehicle order.
     Works for any backend (RCCL on GPU tensors, gloo on CPU tensors).  Returns the full tensor on
@@ -40,7 +50,7 @@ def gather_in_order(local: torch.Tensor, n_items: int, group=None, dst: int = 0)
     reused by every later call (a frame loop calls this once per pass): the result is a fresh tensor, the staging
     buffers never escape."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _one_rank(group):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_range(n_items, r, world) for r in range(world)]
@@ -73,7 +83,7 @@ def broadcast_state_dicts(state_dicts: Optional[Dict[str, dict]], nets: Sequence
     with RCCL ("nccl") the blobs are staged on `device` (default: the current HIP device), with gloo on the host.
     Without an initialised process group (or world size 1) it returns rank src's dicts unchanged."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _one_rank(group):
         assert state_dicts is not None, "broadcast_state_dicts: no process group and no state_dicts"
         return {n: state_dicts[n] for n in nets}
     rank = dist.get_rank(group)
@@ -155,7 +165,7 @@ class VehiclePipeline:
         self.cad = None
         if broadcast_src is not None:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if not _one_rank(group):
                 nets_ = ("hg", "icn", "vunet") + (("edge", "inpaint") if inpaint else ())
                 coll_dev = self.device if dist.get_backend(group) == "nccl" else "cpu"
                 state_dicts = broadcast_state_dicts(state_dicts if dist.get_rank(group) == broadcast_src else None,
@@ -437,7 +447,7 @@ class VehiclePipeline:
         rng = torch.get_rng_state() if check == "sync" else None
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1 and scene.get("shard", True):
+        if not _one_rank(self.group) and scene.get("shard", True):
             # One frame's vehicles over the ranks (BASELINE configs[3]: 64 vehicles of a frame, 8 shards of 8):
             # every rank holds the scene and renders vehicles shard_range(V, rank, world); the uint8 crops, keypoint indices
             # and crop rows travel to rank 0 (gather_in_order: five small messages per frame, no other exchange), which fits
@@ -467,7 +477,7 @@ class VehiclePipeline:
         is the caller's (nothing aliases a later frame's buffers).  A frame whose split-fp16 range status is raised is
         redone in exact fp32 before it is yielded, with the RNG state it was issued under."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if not _one_rank(self.group):
             # sharded frames, one frame deep as well: every rank issues its shard of frame i+1 before frame i's crops are
             # gathered; the gather and rank 0's frame-level part run on a communication stream that waits for frame i's
             # launches only, so they overlap frame i+1's networks.  Yields `run_frame`'s sharded results (rank 0: the frame,
@@ -780,8 +790,7 @@ class VehiclePipeline:
         Returns 'icn_u8' / 'vunet_u8' uint8 [V, R, R, 3] (BGR), 'frame_icn' / 'frame_vunet' uint8 [H, W, 3], 'geom'."""
         rng = torch.get_rng_state() if (check == "sync" and scene.get("vehicle_seeds") is None) else None
         import torch.distributed as dist
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1 and state.get("sharded"):
+        if not _one_rank(self.group) and state.get("sharded"):
             # a clip sharded over ranks (north_star: "vehicles-in-a-frame and frames-in-a-clip shard"): every rank passes the
             # same scene and ITS OWN state (run_frame's, rank-local); it renders its vehicles [lo, hi) from the appearance codes
             # it kept, the uint8 crops and crop rows travel to rank 0, which pastes in vehicle order.  As for the first

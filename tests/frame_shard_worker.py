@@ -28,13 +28,28 @@ BARS = {"vunet_u8": (1, 2e-4), "icn_u8": (8, 1e-3), "frame_icn": (6, 2e-4), "fra
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.set_num_threads(8)                                          # two ranks share the box's host
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("FUSG_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        # RCCL: one card per rank.  On a box with ONE card the test starts a single rank with FUSG_DIST_FORCE=1 - the sharded code
+        # paths then run with a one-rank RCCL communicator (every shard is the whole frame: the results equal the unsharded ones bit for bit)
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank % torch.cuda.device_count()))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from future_urban_scene_generation_amd import ops
     from future_urban_scene_generation_amd.pipeline import VehiclePipeline, shard_range, synth_frame, synth_later_frame as later_scene
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", rank % torch.cuda.device_count()) if backend == "nccl" else torch.device("cuda:0")
     ops.set_precision("f16x3")
     inpaint = len(sys.argv) > 1 and sys.argv[1] == "inpaint"
-    pipe = VehiclePipeline(dev, inpaint=inpaint, seed=3)
+    if backend == "nccl":
+        # the start-up collective as well: rank 0's weights reach every rank as one flat device blob per network (north_star)
+        from future_urban_scene_generation_amd.pipeline import load_schema
+        from future_urban_scene_generation_amd.synth import synth_state_dict
+        nets = ("hg", "icn", "vunet") + (("edge", "inpaint") if inpaint else ())
+        mine = {n: synth_state_dict(n, load_schema(n), 3) for n in nets} if rank == 0 else None
+        pipe = VehiclePipeline(dev, inpaint=inpaint, state_dicts=mine, broadcast_src=0)
+    else:
+        pipe = VehiclePipeline(dev, inpaint=inpaint, seed=3)
     ok = True
     obs = {}
 
@@ -60,6 +75,8 @@ def main():
         st = got["state"]
         assert st["sharded"] and st["shard"] == (lo, hi, V) and st["central"].shape[0] == hi - lo and st["appearance"][0].shape[0] == hi - lo
         assert (set(got) == {"state"}) == (rank != 0)
+        if world == 1:
+            assert dist.get_backend() == "nccl" and os.environ.get("FUSG_DIST_FORCE") == "1"
         later = later_scene(sc, 7)
         got_l = pipe.run_later_frame(later, st)                       # the clip's next frame: same shards, codes never moved
         assert (got_l is None) == (rank != 0)

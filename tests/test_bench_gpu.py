@@ -72,3 +72,47 @@ def test_run_frame_sharded_over_two_ranks():
     assert obs
     for k, v in json.loads(obs[-1][4:]).items():
         record("shard_" + k, v)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_collectives_with_a_one_rank_communicator():
+    """RCCL itself, as far as a box with ONE card can run it (two ranks cannot share a card under RCCL): a single rank with
+    FUSG_DIST_FORCE=1 takes every multi-rank code path - `broadcast_state_dicts` (flat device blobs), the sharded `run_frame` /
+    `run_later_frame` / pipelined `run_frames` / `run_clip_frames` with their gathers on the communication stream - through a
+    one-rank "nccl" communicator.  The shard is the whole frame, so everything must equal the unsharded call (the worker's bars; the
+    integer results bit for bit).  Then `bench.py` the same way: its line says rccl_ranks 1 / dist_backend nccl.  On a box with two or
+    more cards the worker runs as two real RCCL ranks instead."""
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has initialised HIP: worker processes are started only from a process that has not")
+    ncards = torch.cuda.device_count()
+    world = 2 if ncards >= 2 else 1
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), FUSG_TEST_BACKEND="nccl",
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        base["FUSG_DIST_FORCE"] = "1"
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "frame_shard_worker.py")], env={**base, "RANK": str(r)},
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    assert "SHARD_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
+    obs = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("OBS ")][-1][4:])
+    if world == 1:                                           # the shard is the whole frame: nothing may differ
+        assert all(v == 0 for v in obs.values()), obs
+    # bench.py through RCCL: one rank per card that exists
+    env = {k: v for k, v in base.items() if k not in ("WORLD_SIZE", "FUSG_TEST_BACKEND")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--res", "128", "--settle-s", "0", "--no-cpu-baseline", "--no-clip", "--precision", "f16x3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0]
+    assert line["rccl_ranks"] == world and line["dist_backend"] == "nccl" and "dist_ranks" not in line and line["value"] > 0
+    assert line["weights"].startswith("broadcast from rank 0")
