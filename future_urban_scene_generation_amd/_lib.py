@@ -121,6 +121,8 @@ _SIGS = {
     "fusg_plan_next_slot": (C.c_int, [C.c_void_p]),
     "fusg_plan_size": (C.c_int64, [C.c_void_p]),
     "fusg_plan_run": (C.c_int, [C.c_void_p]),
+    "fusg_plan_streams": (C.c_int32, [C.c_void_p]),
+    "fusg_plan_run_mt": (C.c_int, [C.c_void_p]),
     "fusg_plan_graph_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "fusg_plan_graph_nodes": (C.c_int64, [C.c_void_p]),
     "fusg_plan_graph_slot": (C.c_int, [C.c_void_p]),

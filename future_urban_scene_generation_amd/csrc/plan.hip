@@ -14,7 +14,11 @@
 //
 // Contract: every device pointer a recorded call used must stay valid and keep its meaning until the plan is destroyed
 // (the Python side records inside a private torch memory pool and keeps the pool), inputs are refreshed in place.
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "common.h"
 
@@ -36,6 +40,12 @@ struct fusg_plan {
     hipGraphExec_t gexec = nullptr;
     hipEvent_t gslot_ev = nullptr;                  // recorded behind every graph launch: the graph's pinned slot is free once it is reached
     int gslot = 0;
+    // fusg_plan_run_mt: one issuing host thread per recorded stream
+    int device = -1;                                // HIP device of the recording thread (the issuing threads make it current)
+    std::vector<std::vector<int>> lanes;            // op indices per stream, in recorded order (lane 0 = the stream of the first op)
+    std::vector<int> wait_src;                      // per op: for a wait, the index of the record op of its event (-1 otherwise)
+    std::unique_ptr<std::atomic<long>[]> issued;    // per op: for a record, the last run whose record has been issued
+    std::atomic<int> abort{0};                      // a lane failed: waiting lanes stop waiting for its records
 };
 
 namespace fusg {
@@ -78,6 +88,7 @@ extern "C" int fusg_plan_end(fusg_plan* p) {
     FUSG_CHECK(p && g_rec == p, "plan_end: this plan is not recording on this thread");
     g_rec = nullptr;
     p->runs = 1;                                    // the recording pass used slot 0
+    (void)hipGetDevice(&p->device);
     return FUSG_OK;
 }
 
@@ -154,6 +165,148 @@ extern "C" int fusg_plan_run(fusg_plan* p) {
     }
     p->runs += 1;
     return FUSG_OK;
+}
+
+
+// ---- multi-threaded replay ------------------------------------------------------------------------------------------
+// At small batches the GPU finishes a pass faster than ONE host thread can issue it: at batch 1 the 299 operations of a crop pass
+// take 1.98 ms to issue (6.6 us each: hipLaunchKernel) and 2.02 ms to run (profiles/r04_small_batch.jsonl) - the pass is bound by the
+// issuing thread, and so is the frame driver (5.8 ms of issue for a 7.4 ms frame).  A pass runs on 4-5 HIP streams
+// (one per network branch), and the runtime's launch path is per stream: fusg_plan_run_mt issues every recorded stream from a host
+// thread of its own - the caller's thread takes the first stream, persistent worker threads the others.  Order inside a stream is the
+// recorded order; across streams the only ordering a recording has are its dependencies (event record on one stream, wait on another),
+// and a waiting thread holds its hipStreamWaitEvent back until the recording thread has ISSUED that run's hipEventRecord (an atomic
+// run counter per record operation) - a wait issued before its record would wait for the previous pass's.  Same launches, same
+// streams, same results as fusg_plan_run.
+namespace {
+
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> state{0};                      // 0 idle, 1 job posted, 2 job done
+    bool asleep = false;
+    fusg_plan* p = nullptr;
+    int lane = 0, slot = 0, rc = 0;
+    long run = 0;
+    char err[512] = "";
+};
+
+int run_lane(fusg_plan* p, int lane, long run, int slot) {
+    for (int oi : p->lanes[lane]) {
+        fusg_plan::Op& op = p->ops[oi];
+        switch (op.kind) {
+            case 0: { const int rc = op.fn(op.stream); if (rc != FUSG_OK) return rc; break; }
+            case 1:
+                if (hipEventRecord(op.ev, op.stream) != hipSuccess) { set_error("plan_run_mt: event record failed"); return FUSG_ERR_LAUNCH; }
+                p->issued[oi].store(run, std::memory_order_release);
+                break;
+            case 2: {
+                std::atomic<long>& a = p->issued[p->wait_src[oi]];
+                while (a.load(std::memory_order_acquire) < run) {
+                    if (p->abort.load(std::memory_order_relaxed)) { set_error("plan_run_mt: another stream's issue failed"); return FUSG_ERR_LAUNCH; }
+                    cpu_relax();
+                }
+                if (hipStreamWaitEvent(op.stream, op.ev, 0) != hipSuccess) { set_error("plan_run_mt: stream wait failed"); return FUSG_ERR_LAUNCH; }
+                break;
+            }
+            default:
+                if (hipMemcpyAsync(op.dst, op.src + (size_t)slot * op.slot_stride, op.bytes, hipMemcpyHostToDevice, op.stream) != hipSuccess ||
+                    hipEventRecord(p->events[op.ev0 + slot], op.stream) != hipSuccess) { set_error("plan_run_mt: h2d copy failed"); return FUSG_ERR_LAUNCH; }
+        }
+    }
+    return FUSG_OK;
+}
+
+void worker_main(Worker* w) {
+    for (;;) {
+        // a pass follows a pass within microseconds in a frame loop: spin for a while before going to sleep
+        int spins = 0;
+        while (w->state.load(std::memory_order_acquire) != 1) {
+            if (++spins < 20000) { cpu_relax(); continue; }
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->asleep = true;
+            w->cv.wait(lk, [w] { return w->state.load(std::memory_order_acquire) == 1; });
+            w->asleep = false;
+        }
+        (void)hipSetDevice(w->p->device);
+        w->rc = run_lane(w->p, w->lane, w->run, w->slot);
+        if (w->rc != FUSG_OK) {
+            snprintf(w->err, sizeof w->err, "%s", fusg_last_error());
+            w->p->abort.store(1, std::memory_order_relaxed);
+        }
+        w->state.store(2, std::memory_order_release);
+    }
+}
+
+std::mutex g_pool_mu;                               // one multi-threaded replay at a time (the workers are shared by all plans)
+std::vector<Worker*> g_pool;                        // never destroyed: the threads end with the process
+
+}  // namespace
+
+extern "C" int32_t fusg_plan_streams(fusg_plan* p) {
+    if (!p || g_rec == p || p->ops.empty()) return -1;
+    if (p->lanes.empty()) {
+        std::vector<hipStream_t> streams;
+        p->wait_src.assign(p->ops.size(), -1);
+        p->issued.reset(new std::atomic<long>[p->ops.size()]);
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            p->issued[i].store(0, std::memory_order_relaxed);
+            const fusg_plan::Op& op = p->ops[i];
+            size_t l = 0;
+            while (l < streams.size() && streams[l] != op.stream) ++l;
+            if (l == streams.size()) { streams.push_back(op.stream); p->lanes.emplace_back(); }
+            p->lanes[l].push_back((int)i);
+            if (op.kind == 2) {                     // its record: the latest earlier record op of the same event
+                for (size_t j = i; j-- > 0;)
+                    if (p->ops[j].kind == 1 && p->ops[j].ev == op.ev) { p->wait_src[i] = (int)j; break; }
+                if (p->wait_src[i] < 0) { p->lanes.clear(); set_error("plan_streams: a wait without an earlier record"); return -1; }
+            }
+        }
+    }
+    return (int32_t)p->lanes.size();
+}
+
+extern "C" int fusg_plan_run_mt(fusg_plan* p) {
+    FUSG_CHECK(p && !g_rec, "plan_run_mt: null plan or a recording is open on this thread");
+    const int nl = fusg_plan_streams(p);
+    FUSG_CHECK(nl >= 1, "plan_run_mt: empty plan");
+    if (nl == 1) return fusg_plan_run(p);
+    std::lock_guard<std::mutex> pool_lock(g_pool_mu);
+    while ((int)g_pool.size() < nl - 1) {
+        Worker* w = new Worker();
+        w->th = std::thread(worker_main, w);
+        w->th.detach();
+        g_pool.push_back(w);
+    }
+    const int slot = p->nslots ? (int)(p->runs % p->nslots) : 0;
+    const long run = p->runs + 1;
+    p->abort.store(0, std::memory_order_relaxed);
+    for (int l = 1; l < nl; ++l) {
+        Worker* w = g_pool[l - 1];
+        w->p = p; w->lane = l; w->slot = slot; w->run = run; w->rc = FUSG_OK;
+        bool wake;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->state.store(1, std::memory_order_release);
+            wake = w->asleep;
+        }
+        if (wake) w->cv.notify_one();
+    }
+    int rc = run_lane(p, 0, run, slot);
+    char err[512] = "";
+    if (rc != FUSG_OK) { snprintf(err, sizeof err, "%s", fusg_last_error()); p->abort.store(1, std::memory_order_relaxed); }
+    for (int l = 1; l < nl; ++l) {
+        Worker* w = g_pool[l - 1];
+        while (w->state.load(std::memory_order_acquire) != 2) cpu_relax();
+        if (w->rc != FUSG_OK && rc == FUSG_OK) { rc = w->rc; snprintf(err, sizeof err, "%s", w->err); }
+        w->state.store(0, std::memory_order_release);
+    }
+    p->runs += 1;
+    if (rc != FUSG_OK) set_error("%s", err);
+    return rc;
 }
 
 

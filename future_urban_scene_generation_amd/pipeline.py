@@ -124,6 +124,8 @@ def load_schema(net: str):
     return OrderedDict((k, (tuple(v[0]), v[1])) for k, v in raw.items())
 
 
+# FUSG_PLAN_MT=1: a recorded pass is replayed by one host thread per recorded stream (fusg_plan_run_mt) instead of one thread for all
+PLAN_THREADS = os.environ.get("FUSG_PLAN_MT", "0") == "1"
 FRAME_PLANS = int(os.environ.get("FUSG_FRAME_PLANS", "6"))     # recorded passes kept by run_frame(replay=True), one per vehicle count
 
 PER_VEHICLE_KEYS = ("bboxes", "masks", "src_sketch", "dst_sketch", "src_planes", "src_kp", "dst_kp", "src_vis", "dst_vis", "kp3d",
@@ -1004,7 +1006,10 @@ class CompiledPass:
         gens = vu.__dict__.get("_vehicle_gens")
         for ring, shapes in self.rec.noise_slots:                             # the reference's draw order
             vu._fill_noise(ring[slot], shapes, gens)
-        L.check(lib.fusg_plan_run(self.rec.handle), "plan_run")
+        if PLAN_THREADS:
+            L.check(lib.fusg_plan_run_mt(self.rec.handle), "plan_run_mt")     # one issuing host thread per recorded stream
+        else:
+            L.check(lib.fusg_plan_run(self.rec.handle), "plan_run")
         return self.outputs
 
     # ---- the recording as one hipGraph: a measurement path (tools/graph_capture_probe.py), not used by the product

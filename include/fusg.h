@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 113
+#define FUSG_VERSION 114
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -454,6 +454,12 @@ int        fusg_plan_add_h2d(fusg_plan* p, void* dst, const void* src, int64_t b
 int        fusg_plan_next_slot(fusg_plan* p);
 int64_t    fusg_plan_size(const fusg_plan* p);    /* recorded operations */
 int        fusg_plan_run(fusg_plan* p);           /* re-issue the recording; asynchronous like the launches themselves */
+/* The same replay issued by ONE HOST THREAD PER RECORDED STREAM (the caller's thread takes the stream of the first operation,
+ * persistent worker threads of the library the others; a wait is held back until its event's record of this run has been issued).
+ * For passes that one issuing thread bounds (small batches: ~300 operations of ~6.6 us of host time each).  Same launches, streams and
+ * results as fusg_plan_run; returns when every stream's operations have been issued.  fusg_plan_streams: recorded streams (-1: none). */
+int32_t    fusg_plan_streams(fusg_plan* p);
+int        fusg_plan_run_mt(fusg_plan* p);
 /* The same recording as ONE hipGraph (measurement path; the product replays plans).  fusg_plan_graph_capture
  * re-issues the recording under a thread-local stream capture begun on `capture_stream` (the stream the pass was recorded
  * from; the recorded dependencies fork and join the side streams) and instantiates the graph; its h2d copies read pinned
