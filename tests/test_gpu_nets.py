@@ -494,6 +494,20 @@ def test_compiled_pass_replays_the_eager_pass(precision):
     torch.manual_seed(4)
     got = cp.run(b1)
     assert all(torch.equal(got[k], want[k]) for k in want)
+    # the same recording issued by one host thread per recorded stream (fusg_plan_run_mt; FUSG_PLAN_MT=1 makes it the default)
+    from future_urban_scene_generation_amd import _lib as L, pipeline as pl
+    assert L.lib().fusg_plan_streams(cp.rec.handle) >= 3                     # hourglass / ICN / VUnet branches (+ the VUnet's shape encoder)
+    old = pl.PLAN_THREADS
+    pl.PLAN_THREADS = True
+    try:
+        for rep in range(3):                                                  # (back to back: the worker threads are reused)
+            for batch, seeds in ((b1, [9, 10]), (b0, [7, 8])):
+                want = {k: v.clone() for k, v in pipe.run(batch, vehicle_seeds=seeds).items()}
+                got = cp.run(batch, vehicle_seeds=seeds)
+                for k in want:
+                    assert torch.equal(got[k], want[k]), (k, rep)
+    finally:
+        pl.PLAN_THREADS = old
     with pytest.raises(ValueError):
         cp.run({k: v[:1] for k, v in b0.items()})
     if precision == "f16x3":
