@@ -86,12 +86,14 @@ def test_rccl_collectives_with_a_one_rank_communicator():
     FUSG_DIST_FORCE=1 takes every multi-rank code path - `broadcast_state_dicts` (flat device blobs), the sharded `run_frame` /
     `run_later_frame` / pipelined `run_frames` / `run_clip_frames` with their gathers on the communication stream - through a
     one-rank "nccl" communicator.  The shard is the whole frame, so everything must equal the unsharded call (the worker's bars; the
-    integer results bit for bit).  Then `bench.py` the same way: its line says rccl_ranks 1 / dist_backend nccl.  On a box with two or
-    more cards the worker runs as two real RCCL ranks instead."""
+    integer results bit for bit).  Then `bench.py` the same way: its line says rccl_ranks 1 / dist_backend nccl.  With
+    FUSG_TEST_RCCL_RANKS=2 on a box with two or more cards the worker runs as two real RCCL ranks instead."""
     if torch.cuda.is_initialized():
         pytest.skip("this process has initialised HIP: worker processes are started only from a process that has not")
     ncards = torch.cuda.device_count()
-    world = 2 if ncards >= 2 else 1
+    # default: the one-rank form, which is what this suite has been run with; FUSG_TEST_RCCL_RANKS=2 on a box with two or more cards
+    # starts two real RCCL ranks instead (never executed so far: opt-in, so that an untested rendezvous cannot hang the suite)
+    world = 2 if (ncards >= 2 and os.environ.get("FUSG_TEST_RCCL_RANKS") == "2") else 1
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), FUSG_TEST_BACKEND="nccl",
                 HSA_ENABLE_IPC_MODE_LEGACY="0")
