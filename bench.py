@@ -663,8 +663,9 @@ def main():
         cdt = (time.perf_counter() - t1) / NC
         extra["clip_frame_mode"] = {"vehicles": FV, "frames": 6, "ms_per_clip": round(cdt * 1e3, 3), "ms_per_frame": round(cdt * 1e3 / 6, 3),
                                     "vehicle_frames_per_s": round(FV * 6 / cdt, 1),
-                                    "what": "1 run_frame + 5 run_later_frame (no hourglass / pose fit / appearance encoder in the later "
-                                            "frames), one synchronous frame at a time, 8 vehicles on a 720 x 1280 frame"}
+                                    "what": "run_clip_frames: 1 run_frame (synchronous) + 5 later frames through run_later_frames (no hourglass / "
+                                            "pose fit / appearance encoder; one later frame in flight: frame i+1's homography fits and launches "
+                                            "are issued before frame i's range status is read back), 8 vehicles on a 720 x 1280 frame"}
         del scene, scene2
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -886,6 +886,58 @@ class VehiclePipeline:
             out["frame_vunet"] = pu.paste_back_device(back, out["vunet_u8"], out["geom"], scene["masks"])   # :428-445
         return out
 
+    def run_later_frames(self, scenes, state: Dict, replay: bool = False):
+        """`run_later_frame` over the later frames of a clip with ONE frame in flight, like `run_frames` for first frames: frame i+1
+        is issued - its homographies fitted on the host, its launches queued - before frame i's range status is read back (pinned,
+        one event per frame), so the host part of a later frame (1 ms of homography fits) and the read-back overlap the previous
+        frame's networks.  A generator: one `run_later_frame`-shaped dict per scene, in order; a frame whose status is raised is
+        redone in exact fp32 before it is yielded.  A sharded state (process group) is not pipelined: frame by frame."""
+        from . import ops
+        if not _one_rank(self.group) and state.get("sharded"):
+            for sc in scenes:
+                yield self.run_later_frame(sc, state, replay=replay)
+            return
+        pending = None
+        for scene in scenes:
+            guarded = ops.range_guarded()
+            rng = torch.get_rng_state() if (guarded and scene.get("vehicle_seeds") is None) else None
+            word = self.status_word() if guarded else None
+            with torch.cuda.device(self.device):
+                if guarded:
+                    with ops.defer_range_check(), ops.status_scope(word):
+                        out = self._run_later_frame(scene, state, replay)
+                else:
+                    out = self._run_later_frame(scene, state, replay)
+                ring = self.__dict__.setdefault("_later_pins", [])
+                pin = ring.pop() if ring else torch.zeros(1, dtype=torch.int32, pin_memory=True)
+                if guarded:
+                    pin.copy_(word[:1], non_blocking=True)
+                    word.zero_()
+                ev = torch.cuda.Event()
+                ev.record()
+            ticket = {"out": out, "pin": pin, "event": ev, "scene": scene, "rng": rng, "guarded": guarded}
+            if pending is not None:
+                yield self._collect_later(pending, state)
+            pending = ticket
+        if pending is not None:
+            yield self._collect_later(pending, state)
+
+    def _collect_later(self, t, state):
+        from . import ops
+        t["event"].synchronize()
+        hit = t["guarded"] and int(t["pin"][0]) != 0
+        self.__dict__["_later_pins"].append(t["pin"])
+        if not hit:
+            return t["out"]
+        cur = torch.get_rng_state()                                # rare: this frame again, in exact fp32
+        if t["rng"] is not None:
+            torch.set_rng_state(t["rng"])
+        with ops.defer_range_check(), ops.precision("f32"):
+            out = self.run_later_frame(t["scene"], state, check=None, replay=False)
+        if t["rng"] is not None:
+            torch.set_rng_state(cur)
+        return out
+
     def run_clip_frames(self, first_scene: Dict, later_scenes, replay: bool = False):
         """A vehicle clip the reference's way (trajectory_inference.py:55-250 then :267-450): the first frame through
         `run_frame`, every future frame through `run_later_frame` with the first frame's state.  Generator of 1 + len(later_scenes)
@@ -893,8 +945,7 @@ class VehiclePipeline:
         first = self.run_frame(first_scene, replay=replay)
         state = first["state"]
         yield first if len(first) > 1 else None
-        for sc in later_scenes:
-            yield self.run_later_frame(sc, state, replay=replay)
+        yield from self.run_later_frames(later_scenes, state, replay=replay)       # one later frame in flight
 
     def run_clip(self, clip: Dict[str, torch.Tensor], vehicle_seeds: Optional[Sequence[int]] = None,
                  check: Optional[str] = "sync") -> Dict[str, torch.Tensor]:

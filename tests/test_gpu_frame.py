@@ -482,6 +482,29 @@ def test_run_later_frame_matches_the_oracle():
     assert rep1["vunet_u8"].data_ptr() != rep2["vunet_u8"].data_ptr()
     clip = list(pipe.run_clip_frames(first, [later, later], replay=True))
     assert len(clip) == 3 and torch.equal(clip[2]["frame_vunet"], got["frame_vunet"]) and torch.equal(clip[0]["kp_idx"], f0["kp_idx"])
+    # later frames with one frame in flight (run_later_frames: what run_clip_frames uses) == one synchronous frame at a time, eager and
+    # replayed; a frame outside the split-fp16 range comes back redone in fp32 (== the synchronous call's result)
+    from future_urban_scene_generation_amd import ops
+    from future_urban_scene_generation_amd.pipeline import synth_later_frame
+    later2 = synth_later_frame(later, 3)
+    for rp in (False, True):
+        want = [pipe.run_later_frame(sc, f0["state"], replay=rp) for sc in (later, later2, later)]
+        seq = list(pipe.run_later_frames([later, later2, later], f0["state"], replay=rp))
+        assert len(seq) == 3
+        for a, b in zip(seq, want):
+            for k in ("icn_u8", "vunet_u8", "frame_icn", "frame_vunet", "geom"):
+                assert torch.equal(a[k], b[k]), (k, rp)
+    hot = dict(later2)
+    hot["dst_sketch"] = later2["dst_sketch"].clone()
+    hot_state = dict(f0["state"])
+    hot_state["appearance"] = [t.clone() for t in f0["state"]["appearance"]]
+    hot_state["appearance"][1][0, 0, 0, 0] = 6e4                                # outside the split-fp16 range: status word raised
+    want = [pipe.run_later_frame(sc, hot_state) for sc in (later, hot)]
+    seq = list(pipe.run_later_frames([later, hot], hot_state))
+    for a, b in zip(seq, want):
+        for k in ("icn_u8", "vunet_u8", "frame_vunet"):
+            assert torch.equal(a[k], b[k]), k
+    assert not ops.range_exceeded(DEV)
     with pytest.raises(ValueError):
         pipe.run_later_frame(synth_frame(1, (360, 640), DEV, seed=43), f0["state"])
 
