@@ -79,6 +79,35 @@ def test_single_process_is_identity():
     assert gather_in_order(x, 3) is x
 
 
+def _force_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FUSG_DIST_FORCE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x = _fake_render([0, 1, 2])
+        got = gather_in_order(x, 3)                                       # through the collective, not the shortcut
+        from future_urban_scene_generation_amd.synth import synth_state_dict
+        want = {"icn": synth_state_dict("icn", load_schema("icn"), 5)}
+        sd = broadcast_state_dicts(want, nets=("icn",), src=0)
+        ok = got is not x and torch.equal(got, x) and all(torch.equal(sd["icn"][k], want["icn"][k]) for k in want["icn"])
+        os.environ.pop("FUSG_DIST_FORCE")
+        ok = ok and gather_in_order(x, 3) is x                            # the shortcut again
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_takes_the_collectives_when_forced():
+    """FUSG_DIST_FORCE=1 (the hook behind tests/test_bench_gpu.py::test_rccl_collectives_with_a_one_rank_communicator): a process group
+    of ONE rank goes through gather / broadcast instead of the single-process shortcuts - same results."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
 def test_vehicle_noise_streams_are_shard_invariant():
     """Host half of the 8(e) noise caveat: with one generator per vehicle the draws of vehicle v are the
     same whatever batch it sits in; without (reference mode) they are `torch.randn(*shape)` on the global RNG."""
