@@ -271,10 +271,10 @@ extern "C" int32_t fusg_plan_streams(fusg_plan* p) {
 
 extern "C" int fusg_plan_run_mt(fusg_plan* p) {
     FUSG_CHECK(p && !g_rec, "plan_run_mt: null plan or a recording is open on this thread");
+    std::lock_guard<std::mutex> pool_lock(g_pool_mu);                 // (also guards the lazy stream split of fusg_plan_streams)
     const int nl = fusg_plan_streams(p);
     FUSG_CHECK(nl >= 1, "plan_run_mt: empty plan");
     if (nl == 1) return fusg_plan_run(p);
-    std::lock_guard<std::mutex> pool_lock(g_pool_mu);
     while ((int)g_pool.size() < nl - 1) {
         Worker* w = new Worker();
         w->th = std::thread(worker_main, w);
