@@ -13,3 +13,12 @@ hipError_t launch_halo_128(const HaloK& k, dim3 grid, hipStream_t s, int pk, int
 #endif
 }
 }  // namespace fusg
+#ifdef FUSG_HALO_STAMPS
+extern "C" int fusg_debug_halo_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fusg::g_halo_stamps), sizeof(unsigned long long) * 64 * 4 * 40) == hipSuccess ? 0 : 1;
+}
+extern "C" int fusg_debug_halo_stamps_clear(void) {
+    static unsigned long long z[64 * 4 * 40];
+    return hipMemcpyToSymbol(HIP_SYMBOL(fusg::g_halo_stamps), z, sizeof z) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -56,6 +56,15 @@ namespace fusg {
 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
+// Diagnostic build only (-DFUSG_HALO_STAMPS on conv_halo_128.hip, tools/halo_stamps.py): s_memtime of every wave of the first 64 workgroups at
+// the boundaries of each chunk (first tap issued / last tap issued / next chunk committed), into a buffer nothing else reads.
+#ifdef FUSG_HALO_STAMPS
+__device__ unsigned long long g_halo_stamps[64 * 4 * 40];
+#define FUSG_HSTAMP(slot) do { if (blockIdx.x < 64 && (slot) < 40 && lane == 0) g_halo_stamps[(blockIdx.x * 4 + wave) * 40 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FUSG_HSTAMP(slot) do {} while (0)
+#endif
+
 constexpr int HALO_CH = 32;          // channels per staged chunk = k per MFMA
 constexpr int HALO_PP = 32;          // halo pixel pitch in halves (64 B, slots swizzled - see above)
 
@@ -113,8 +122,22 @@ constexpr int halo_waves(int, int) { return FUSG_HALO_WAVES; }
 // fragments, and ~60 bookkeeping instructions per step - so those launches ran at an MFMA-pipe busy of 0.22-0.30
 // (profiles/r03_pmc_narrow_layers.txt); here a step is 48 MFMAs like on the 128-column tile, every wave fetches different
 // weight fragments, and the per-step overhead is paid a quarter as often.  It pays on small grids only (conv_igemm.hip).
+// bf16 mode: THREE (FUSG_BF16_OCC=4: four) waves per SIMD.  A bf16 step is 16 MFMAs = 256 cycles of matrix pipe per wave and ~1000 cycles of
+// wave time (tools/halo_stamps.py: the gaps are the step's own instruction stream and, once per chunk, the wait behind the next chunk's halo
+// gather - loads return in order); two waves per SIMD leave the pipe half idle inside the taps, a third fills it.  Needs <= 168 VGPRs (the
+// instantiations that would spill keep two waves) and the epilogue's LDS detour in two halves (32 KiB per workgroup instead of 64).
+#ifndef FUSG_BF16_OCC
+#define FUSG_BF16_OCC 3
+#endif
+constexpr bool halo_bf16_dense(int tm, int wm, int pk, int ni, int mode, int ks) {
+    return FUSG_BF16_OCC > 2 && mode == 1 && ks == 1 && 32 * tm * wm == 128 &&
+           !(tm == 4 && ((pk == PK_AFFINE && ni >= 8) || (pk == PK_NONE && ni >= 10)));      // (these spill at 168 registers)
+}
+constexpr int halo_waves_mode(int tm, int tn, int wm, int pk, int ni, int mode, int ks) {
+    return halo_bf16_dense(tm, wm, pk, ni, mode, ks) ? FUSG_BF16_OCC : halo_waves(tm, tn);
+}
 template <int TM, int TN, int WM, int WN, int PK, int NI, int MODE, int KS = 1>
-__global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)) void conv_halo_h3(const HaloK hk) {
+__global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves_mode(TM, TN, WM, PK, NI, MODE, KS)) void conv_halo_h3(const HaloK hk) {
     constexpr bool BF = MODE == 1, F32 = MODE == 2;
     constexpr int CH = HALO_CH, HPITCH = HALO_PP;
     constexpr int CPP = CH / 4;                    // 16-byte fp32 items per halo pixel
@@ -136,6 +159,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
+    FUSG_HSTAMP(0);
     const int wk = wave / (WM * WN);               // K-split index (0 when KS == 1)
     const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
     const int kc = t & (CPP - 1);
@@ -455,18 +479,24 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
     halo_commit(hA);
     __syncthreads();
     auto one_step = [&](const BFrag& use, BFrag& fill) __attribute__((always_inline)) {
+        if (tap == 0) FUSG_HSTAMP(1 + 3 * cg);
+        if (cg == 1) FUSG_HSTAMP(30 + tap);                        // (diagnostic: every tap of the second chunk)
         if (tap == 0 && cg + 1 < nch) {                            // in flight during all taps of this chunk
             next_halo_chunk();
             halo_issue(hA, cg + 1, qh, cqh);
         }
+        if (cg == 1 && tap < 2 && nch <= 6) FUSG_HSTAMP(20 + 4 * tap);   // (slots 20.. belong to the chunk stamps of deeper layers)
         advance_w();                                               // the step fetched now: one (bf16: two) ahead
         if (cgn < nch) b_load(fill, wnext);
+        if (cg == 1 && tap < 2 && nch <= 6) FUSG_HSTAMP(21 + 4 * tap);
         int dyp = ky * hk.dil, dxp = kx * hk.dil;                  // halo pixel offset of the tap
         if (s2d) { dyp = hk.qtdy[qc & 3][tap]; dxp = hk.qtdx[qc & 3][tap]; }
         compute(dyp, dxp, use);
+        if (cg == 1 && tap < 2 && nch <= 6) FUSG_HSTAMP(22 + 4 * tap);
         ++tap;
         if (++kx == hk.kw) { kx = 0; ++ky; }
         if (tap == ntc) {
+            FUSG_HSTAMP(2 + 3 * cg);
             tap = 0; ky = 0; kx = 0;
             if (s2d) { if (++cqc == nchq) { cqc = 0; ++qc; } ntc = hk.qtaps[qc & 3]; }
             if (++cg < nch) {
@@ -474,6 +504,7 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
                 halo_commit(hA);
                 __syncthreads();
             }
+            FUSG_HSTAMP(3 * cg);
         }
     };
     if constexpr (RING3) {
@@ -555,7 +586,8 @@ __global__ __launch_bounds__(256, (32 * TM * WM == 256) ? 1 : halo_waves(TM, TN)
         return p.stats + ((long)b * p.stats_slots + t2 * (BM / 32) + ((wm * TM * 32) >> 5) + i) * p.Cout * 2;
     };
     if (p.vec_epi) {
-        if constexpr (BM == 256) {
+        constexpr bool HALVES = BM == 256 || (TM >= 4 && halo_bf16_dense(TM, WM, PK, NI, MODE, KS));
+        if constexpr (HALVES) {
             // the wave's tile (TM * 32 rows) leaves in two halves through a wave-private LDS region of half the size (64 KiB per
             // workgroup instead of 128: two workgroups still share a CU); residuals are read in the pass, not prefetched
             // (the prefetch set would be 128 more registers)
@@ -616,7 +648,12 @@ template <int TM, int TN, int WM, int WN, int KS = 1>
 hipError_t launch_halo(const HaloK& k, dim3 grid, hipStream_t s, int pk, int mode) {      // mode: 0 split-fp16, 1 bf16, 2 exact fp32
     const int HP = k.HH * k.HW;
     size_t lds = halo_lds_bytes(k.HH, k.HW);
-    if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour (K split: the four partial tiles)
+    size_t epi = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);                                                     // epilogue detour (K split: the four partial tiles)
+    {   // bf16 at three waves per SIMD: the tile leaves in two halves (exactly the instantiations halo_bf16_dense() names)
+        const int nit = (HP * 8 + 255) / 256 <= 6 ? 6 : ((HP * 8 + 255) / 256 <= 8 ? 8 : 10);
+        if (TM >= 4 && halo_bf16_dense(TM, WM, pk, nit, mode, KS)) epi /= 2;
+    }
+    if (lds < epi) lds = epi;
     const int touch_off = (int)lds;
     lds += TOUCH_LDS_BYTES;
     const int ni = (HP * 8 + 255) / 256;
