@@ -557,6 +557,9 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             h.nunits = nunits; h.nsteps = (nunits + 16 / unit - 1) / (16 / unit);
             h.wfrag = (const _Float16*)d->wfrag;
             h.nt32 = d->cout_pad / 32;
+            // FUSG_PREC_BF16: the stem in single-pass bf16 too (wfrag_bf16 in the tap-unit form, pack.py: frag_tapunit_bf16)
+            const bool tbf = want_bf16 && d->wfrag_bf16 != nullptr && (((uintptr_t)d->wfrag_bf16) & 15) == 0 && getenv("FUSG_NO_BF16_TAPUNIT") == nullptr;
+            if (tbf) { h.wfrag = (const _Float16*)d->wfrag_bf16; h.c.wscale = nullptr; h.c.status = nullptr; }
             const int upp = d->c0k / unit;
             for (int j = 0; j < nunits; ++j) {
                 const int tap = j / upp, u = j - tap * upp, ky = tap / d->kw, kx = tap - ky * d->kw;
@@ -572,10 +575,10 @@ static int conv2d_impl(const fusg_conv_desc* din, void* stream) {
             h.c.ksplit = 1;
             if (tapunit_lds_bytes(h.HH, h.RP) <= 80 * 1024 && h.HH * h.HW * (h.CP / 4) <= 256 * 8) {
                 dim3 hgrid(h.c.MT * h.c.NT, 1, 1);
-                e = bn == 128 ? launch_tapunit_128(h, hgrid, s, pk, unit) : bn == 64 ? launch_tapunit_64(h, hgrid, s, pk, unit)
-                                                                                     : launch_tapunit_32(h, hgrid, s, pk, unit);
+                e = bn == 128 ? launch_tapunit_128(h, hgrid, s, pk, unit, tbf) : bn == 64 ? launch_tapunit_64(h, hgrid, s, pk, unit, tbf)
+                                                                                          : launch_tapunit_32(h, hgrid, s, pk, unit, tbf);
                 if (e != hipSuccess) { set_error("conv2d tap-unit launch: %s", hipGetErrorString(e)); prof_end(0, s); return FUSG_ERR_LAUNCH; }
-                note_conv_kernel(FUSG_CONV_TAPUNIT);
+                note_conv_kernel(tbf ? FUSG_CONV_TAPUNIT_BF16 : FUSG_CONV_TAPUNIT);
                 prof_end(0, s);
                 return FUSG_OK;
             }

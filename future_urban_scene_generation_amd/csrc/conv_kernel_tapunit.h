@@ -10,6 +10,9 @@
 // LDS read at pixel offset + uoff[unit]; the table of unit offsets comes in through the kernel arguments.
 // ICN stem: 49 taps x 3 units = 147 units = 74 k-steps instead of 98; EdgeConnect / hourglass stems: 13 k-steps.
 // Weights: pack.py stores them per k-step in MFMA-fragment order (frag_tapunit), zero where a unit is padding.
+// MODE 1 (round 4, FUSG_PREC_BF16: the stems of BASELINE configs[4]'s "bf16 MFMA conv path"): the same kernel with ONE bf16 product per
+// operand pair - activations rounded to bf16 while they are staged (one LDS image), weights pre-rounded (pack.py: frag_tapunit_bf16,
+// [step][cout_pad/32][64 lanes][8]), v_mfma_f32_32x32x16_bf16, no weight scales, no range status.
 #pragma once
 #include "conv_kernel_halo.h"
 
@@ -23,13 +26,14 @@ struct TapUnitK {
     int pad_h, pad_w, stride;
     int tiles_x, tiles_per_img;
     int nunits, nsteps;         // real units, k-steps = ceil(nunits / (16 / U))
-    const _Float16* wfrag;      // [step][cout_pad/32][hi|lo][64 lanes][8] halves
+    const _Float16* wfrag;      // [step][cout_pad/32][hi|lo][64 lanes][8] halves (MODE 1: [step][cout_pad/32][64 lanes][8] bf16)
     int nt32;
     int uoff[160];              // LDS offset (halves) of each unit relative to the output pixel's halo origin
 };
 
-template <int TM, int TN, int WM, int WN, int PK, int U>
+template <int TM, int TN, int WM, int WN, int PK, int U, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
+    constexpr bool BF = MODE == 1;
     const ConvK& p = hk.c;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -106,17 +110,26 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const float y = fmaf(v[c], sc[c], sh[c]); v[c] = ok ? y : 0.f; }
             }
-            h4 hi, lo;
-            if constexpr (PK == PK_ELU) split4<false>(v, vfloor, hi, lo, amax); else split4(v, vfloor, hi, lo, amax);
-            *(h4*)(Ah + hoff[j]) = hi;
-            *(h4*)(Al + hoff[j]) = lo;
+            if constexpr (BF) {
+                if (vfloor == 0.f) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaxf(v[c], 0.f);
+                }
+                *(bf4*)(Ah + hoff[j]) = __builtin_convertvector(v, bf4);
+            } else {
+                h4 hi, lo;
+                if constexpr (PK == PK_ELU) split4<false>(v, vfloor, hi, lo, amax); else split4(v, vfloor, hi, lo, amax);
+                *(h4*)(Ah + hoff[j]) = hi;
+                *(h4*)(Al + hoff[j]) = lo;
+            }
         }
-        report_range(p, amax);
+        if constexpr (!BF) report_range(p, amax);
     }
 
     // this wave's weight fragments: column tiles (nt*BN/32 + wn*TN + j), j < TN
-    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * 2 * 64 + lane) * 8;
-    const long wstep = (long)hk.nt32 * 2 * 64 * 8;                 // halves per k-step slab
+    constexpr int FPT = BF ? 1 : 2;                                // fragments per 32-column tile and k-step: [hi | lo] or one bf16
+    const _Float16* wfr = hk.wfrag + ((long)(nt * (BN / 32) + wn * TN) * FPT * 64 + lane) * 8;
+    const long wstep = (long)hk.nt32 * FPT * 64 * 8;               // 16-bit elements per k-step slab
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -134,13 +147,13 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
     }
     const int g = lane >> 5;
 
-    struct BFrag { h8 f[TN][2]; };
+    struct BFrag { h8 f[TN][FPT]; };
     auto b_load = [&](BFrag& F, int step) {
         const _Float16* base = wfr + (long)step * wstep;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl) F.f[j][hl] = *(const h8*)(base + (j * 2 + hl) * 512);
+            for (int hl = 0; hl < FPT; ++hl) F.f[j][hl] = *(const h8*)(base + (j * FPT + hl) * 512);
     };
     BFrag bfA, bfB;
     b_load(bfA, 0);
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = live ? *(const h8*)(Ah + abase[i] + off) : zero8;
-                al[i] = live ? *(const h8*)(Al + abase[i] + off) : zero8;
+                if constexpr (!BF) al[i] = live ? *(const h8*)(Al + abase[i] + off) : zero8;
             }
         } else {
             const int j = step * 4, last = hk.nunits - 1;
@@ -170,23 +183,33 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const h4 a0 = l0 ? *(const h4*)(Ah + abase[i] + oa) : zero4, a1 = l1 ? *(const h4*)(Ah + abase[i] + ob) : zero4;
-                const h4 c0 = l0 ? *(const h4*)(Al + abase[i] + oa) : zero4, c1 = l1 ? *(const h4*)(Al + abase[i] + ob) : zero4;
                 ah[i] = h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                al[i] = h8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                if constexpr (!BF) {
+                    const h4 c0 = l0 ? *(const h4*)(Al + abase[i] + oa) : zero4, c1 = l1 ? *(const h4*)(Al + abase[i] + ob) : zero4;
+                    al[i] = h8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                }
             }
         }
-        h8 bs[TN];                                                 // wh * 2^-11: B operand of the al' term
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bs[j] = scale_m11(F.f[j][0]);
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
+        if constexpr (BF) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i],
-                                                                       term == 0 ? F.f[j][0] : term == 1 ? F.f[j][1] : bs[j],
-                                                                       acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ah[i]), __builtin_bit_cast(bf8, F.f[j][0]), acc[i][j], 0, 0, 0);
+        } else {
+            h8 bs[TN];                                             // wh * 2^-11: B operand of the al' term
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bs[j] = scale_m11(F.f[j][0]);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[i] : ah[i],
+                                                                           term == 0 ? F.f[j][0] : term == 1 ? F.f[j][FPT - 1] : bs[j],
+                                                                           acc[i][j], 0, 0, 0);
+        }
     };
     int step = 0;
     for (; step + 1 < hk.nsteps; step += 2) {
@@ -239,13 +262,14 @@ __global__ __launch_bounds__(256, 2) void conv_tapunit_h3(const TapUnitK hk) {
 inline size_t tapunit_lds_bytes(int HH, int RP) { return (size_t)2 * HH * RP * sizeof(_Float16); }
 
 template <int TM, int TN, int WM, int WN>
-hipError_t launch_tapunit(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, int unit) {
+hipError_t launch_tapunit(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, int unit, int mode) {       // mode: 0 split-fp16, 1 bf16
     size_t lds = tapunit_lds_bytes(k.HH, k.RP);
     if (lds < (size_t)4 * TM * 32 * TN * 32 * sizeof(float)) lds = (size_t)4 * TM * 32 * TN * 32 * sizeof(float);   // epilogue detour
     if (lds > 80 * 1024) return hipErrorInvalidValue;
     const void* fn = nullptr;
 #define FUSG_PICK_U(PKV)                                                                      \
-    fn = unit == 8 ? (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 8> : (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 4>;
+    fn = mode == 1 ? (unit == 8 ? (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 8, 1> : (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 4, 1>) \
+                   : (unit == 8 ? (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 8, 0> : (const void*)conv_tapunit_h3<TM, TN, WM, WN, PKV, 4, 0>);
     if (pk == PK_NONE) { FUSG_PICK_U(PK_NONE) } else if (pk == PK_ELU) { FUSG_PICK_U(PK_ELU) } else { FUSG_PICK_U(PK_AFFINE) }
 #undef FUSG_PICK_U
     if (hipError_t e = ensure_dyn_lds(fn, 80 * 1024); e != hipSuccess) return e;
@@ -254,8 +278,8 @@ hipError_t launch_tapunit(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, i
     return hipLaunchKernel(fn, grid, dim3(256), args, lds, s);
 }
 
-hipError_t launch_tapunit_128(const TapUnitK&, dim3, hipStream_t, int, int);
-hipError_t launch_tapunit_64(const TapUnitK&, dim3, hipStream_t, int, int);
-hipError_t launch_tapunit_32(const TapUnitK&, dim3, hipStream_t, int, int);
+hipError_t launch_tapunit_128(const TapUnitK&, dim3, hipStream_t, int, int, int);
+hipError_t launch_tapunit_64(const TapUnitK&, dim3, hipStream_t, int, int, int);
+hipError_t launch_tapunit_32(const TapUnitK&, dim3, hipStream_t, int, int, int);
 
 }  // namespace fusg

@@ -1,5 +1,5 @@
 // BN = 64 column tile of the tap-unit convolution for few-channel stems (see conv_kernel_tapunit.h).
 #include "conv_kernel_tapunit.h"
 namespace fusg {
-hipError_t launch_tapunit_64(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, int unit) { return launch_tapunit<2, 1, 2, 2>(k, grid, s, pk, unit); }
+hipError_t launch_tapunit_64(const TapUnitK& k, dim3 grid, hipStream_t s, int pk, int unit, int mode) { return launch_tapunit<2, 1, 2, 2>(k, grid, s, pk, unit, mode); }
 }  // namespace fusg

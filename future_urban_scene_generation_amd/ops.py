@@ -571,7 +571,8 @@ def bottleneck(p: dict, x: torch.Tensor, res: Optional[torch.Tensor] = None, pre
 def last_conv_kernel() -> int:
     """Kernel family of the last conv launch issued by this thread (fusg_last_conv_kernel): 0 generic fp32,
     1 generic split-fp16, 2 halo, 3 halo in parity-quadrant (stride-2) form, 4 tap-unit kernel (few-channel stems),
-    5 halo in bf16 mode, 6 fused hourglass Bottleneck, 7 pointwise-from-few-channels streaming kernel."""
+    5 halo in bf16 mode, 6 fused hourglass Bottleneck, 7 pointwise-from-few-channels streaming kernel, 8 small-image kernel,
+    9 halo in exact fp32, 10 tap-unit in exact fp32, 11 tap-unit in bf16 mode."""
     return int(L.lib().fusg_last_conv_kernel())
 
 

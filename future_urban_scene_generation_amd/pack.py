@@ -68,6 +68,8 @@ class ConvPlan:
             fb = frag_bf16(self.wpack, self) if self.nphase == 1 else None
             if fb is not None and self.s2d_ok():
                 fb = fb[s2d_tap_order(self.kh)].contiguous()
+            if fb is None and frag is not None and self.tapunit_ok():
+                fb = frag_tapunit_bf16(self.wpack, self)               # the stem in single-pass bf16 (tap-unit kernel, MODE 1)
             self.dev["wfrag_bf16"] = None if fb is None else fb.to(device).contiguous()
             self.dev["wfrag_order"] = 1 if self.s2d_ok() else (2 if self.tapunit_ok() else 0)   # fusg_conv_desc.wfrag_order
         return self
@@ -212,6 +214,21 @@ def frag_tapunit(wsplit: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:
     wk = wk.view(2, nt32, 32, nsteps, 2, 8)                     # hl, nt, r, step, h, j
     wk = wk.permute(3, 1, 0, 4, 2, 5)                           # step, nt, hl, h, r, j
     return wk.reshape(nsteps, nt32, 2, 64, 8).contiguous()
+
+
+def frag_tapunit_bf16(wpack: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:
+    """bf16 weights (ties to even) of a few-channel layer in the k-step order of the tap-unit kernel's bf16 mode: `frag_tapunit`
+    without the (hi | lo) axis -> [step][cout_pad/32][64 lanes][8], lane = (k >> 3 & 1) * 32 + column."""
+    w = wpack[0]                                                # [cout_pad, k_pad], K order (tap, channel) with c0k per tap
+    taps, c = plan.kh * plan.kw, plan.c0k
+    k = taps * c
+    nsteps = (k + 15) // 16
+    wk = torch.zeros(plan.cout_pad, nsteps * 16, dtype=torch.float32)
+    wk[:, :k] = w[:, :k]
+    nt32 = plan.cout_pad // 32
+    wk = wk.to(torch.bfloat16).view(nt32, 32, nsteps, 2, 8)     # nt, r, step, h, j
+    wk = wk.permute(2, 0, 3, 1, 4)                              # step, nt, h, r, j
+    return wk.reshape(nsteps, nt32, 64, 8).contiguous()
 
 
 def frag_tapunit_f32(wpack: torch.Tensor, plan: "ConvPlan") -> torch.Tensor:

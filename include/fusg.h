@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FUSG_VERSION 114
+#define FUSG_VERSION 115
 
 typedef enum fusg_status {
     FUSG_OK = 0,
@@ -194,7 +194,9 @@ typedef struct fusg_conv_desc {
     int32_t*       status;
     /* FUSG_PREC_BF16 only: the weights rounded to bf16 (ties to even) in the halo kernel's fragment order
      * [tap][chunk32][cout_pad/32][16-column half][64 lanes][8 bf16], same tap order as `wfrag` (pack.py: frag_bf16).
-     * NULL: the launch runs as F16X3. */
+     * NULL: the launch runs as F16X3.
+     * With wfrag_order 2 (few-channel stems) it holds the tap-unit form instead: [k-step][cout_pad/32][64 lanes][8 bf16], the
+     * `wfrag` layout of that order without the (hi | lo) axis (pack.py: frag_tapunit_bf16). */
     const void*    wfrag_bf16;
     /* FUSG_PREC_F32, optional: the fp32 weights in the halo kernel's fragment order for v_mfma_f32_16x16x4_f32,
      * [tap][chunk32][cout_pad/32][16-column half][h][64 lanes][4 floats] with lane = g * 16 + column holding
@@ -483,7 +485,8 @@ enum { FUSG_CONV_GENERIC_F32 = 0, FUSG_CONV_GENERIC_F16X3 = 1, FUSG_CONV_HALO = 
        FUSG_CONV_POINTWISE = 7 /* 1x1 from <= 8 channels: streaming fp32 FMA kernel, no matrix cores */,
        FUSG_CONV_SMALL = 8 /* small output images (<= 64 pixels): latency-built split-fp16 kernel (csrc/conv_kernel_small.h) */,
        FUSG_CONV_HALO_F32 = 9 /* halo kernel in exact fp32 (v_mfma_f32_16x16x4_f32, fusg_conv_desc.wfrag_f32) */,
-       FUSG_CONV_TAPUNIT_F32 = 10 /* few-channel stems in exact fp32 (csrc/conv_kernel_tapunit_f32.h; wfrag_order 2 + wfrag_f32) */ };
+       FUSG_CONV_TAPUNIT_F32 = 10 /* few-channel stems in exact fp32 (csrc/conv_kernel_tapunit_f32.h; wfrag_order 2 + wfrag_f32) */,
+       FUSG_CONV_TAPUNIT_BF16 = 11 /* few-channel stems in single-pass bf16 (FUSG_PREC_BF16; wfrag_order 2 + wfrag_bf16) */ };
 int         fusg_last_conv_kernel(void);
 const char* fusg_arch(void);                      /* "gfx950" */
 /* sizeof(fusg_tensor) / sizeof(fusg_conv_desc) as compiled, so that FFI bindings can verify their

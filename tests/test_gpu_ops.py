@@ -653,6 +653,42 @@ def test_bf16_halo_conv(cin, cout, k, stride, pad, dil, pm, H, W, pre, precision
     _close(g2, F.conv2d(x2, w2, padding=1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,pm,H,W,pre", [
+    (21, 64, 7, 1, 3, 1, 32, 32, L.PRE_NONE),               # ICN stem: 24 staged channels (units of 8), reflect padding
+    (3, 64, 7, 2, 3, 0, 64, 64, L.PRE_NONE),                # hourglass stem shape: 4 staged channels (units of 4), stride 2
+    (4, 64, 7, 1, 3, 1, 16, 32, L.PRE_ELU),                 # EdgeConnect stem shape with a pre-op
+])
+def test_bf16_tapunit_stems(cin, cout, k, stride, pad, pm, H, W, pre, precision):
+    """FUSG_PREC_BF16 on the few-channel stems (round 4: the tap-unit kernel's bf16 mode, kernel family 11) equals a convolution of
+    bf16-rounded operands with exact products; FUSG_NO_BF16_TAPUNIT keeps the split-fp16 kernel (family 4) under the same setting."""
+    if precision != "f16x3":
+        pytest.skip("one run")
+    import os
+    x = _rand(2, cin, H, W, seed=71)
+    w = _rand(cout, cin, k, k, seed=72, scale=1.0 / (cin * k * k) ** 0.5)
+    b = _rand(cout, seed=73)
+    plan = pack.pack_conv(w, b, stride=stride, pad=pad, pad_mode=pm)
+    assert plan.tapunit_ok()
+    xd = ops.as_nhwc(x.to(dev()), cpad=plan.c0k)
+    xp = F.elu(x) if pre == L.PRE_ELU else x
+    xr, wr = xp.bfloat16().double(), w.bfloat16().double()
+    xin = F.pad(xr, (pad,) * 4, mode="reflect") if pm else xr
+    ref = F.conv2d(xin, wr, b.double(), stride=stride, padding=0 if pm else pad)
+    den = F.conv2d(xin.abs(), wr.abs(), None, stride=stride, padding=0 if pm else pad) + 1e-30
+    got = ops.conv(plan, xd, pre_op=pre, precision="bf16", ksplit=1)
+    assert ops.last_conv_kernel() == 11, ops.last_conv_kernel()
+    assert float(((got.cpu().double() - ref).abs() / den).max()) < (3e-5 if pre == L.PRE_ELU else 3e-6)
+    os.environ["FUSG_NO_BF16_TAPUNIT"] = "1"
+    try:
+        old = ops.conv(plan, xd, pre_op=pre, precision="bf16", ksplit=1)
+        assert ops.last_conv_kernel() == 4
+    finally:
+        del os.environ["FUSG_NO_BF16_TAPUNIT"]
+    exact = F.conv2d(F.pad(xp.double(), (pad,) * 4, mode="reflect") if pm else xp.double(), w.double(), b.double(), stride=stride,
+                     padding=0 if pm else pad)
+    assert float((old.cpu().double() - exact).abs().max() / exact.abs().max()) < 1e-5        # (the split-fp16 result: fp32-class)
+
+
 def test_splitk_in_launch_combine_equals_reduce_kernel(precision, monkeypatch):
     """The opt-in last-arriver combine of split-K launches (csrc/conv_kernel.h, splitk_arrive / splitk_combine; off by
     default because it measured slower than the extra launch, ops.py) against the separate reduce kernel: bit-identical (same slab order), on every launch of a long, unevenly loaded sequence - a big
